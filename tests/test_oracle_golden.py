@@ -1,0 +1,143 @@
+"""CPU: pin oracle/oracle.c against the committed golden vectors (made from the real reference by
+tests/golden/make_golden.py) and against the known answers the reference tree holds."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import DATA, GOLDEN, assert_parity, po, summarize, synth_csr
+
+FX = np.load(os.path.join(GOLDEN, "fixtures.npz"))
+SM = np.load(os.path.join(GOLDEN, "synth_small.npz"))
+META = json.load(open(os.path.join(GOLDEN, "golden.json")))
+
+
+def unpack(z, prefix):
+    r, c = z[prefix + "_shape"]
+    return po.CSRHost(z[prefix + "_rowPtr"], z[prefix + "_colInd"], z[prefix + "_values"], int(r), int(c))
+
+
+def bit_equal(a, b):
+    """Raw arrays identical (same order inside rows, same float bits)."""
+    return (a.rows == b.rows and a.cols == b.cols and np.array_equal(a.rowPtr, b.rowPtr)
+            and np.array_equal(a.colInd, b.colInd)
+            and np.array_equal(a.values.view(np.uint32), b.values.view(np.uint32)))
+
+
+FILES = [n for n in sorted(os.listdir(DATA)) if n != "tdata.snap"]
+SQUARE = [n for n in FILES if "nnzC" in META["fixtures"][n]]
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_loader_matches_reference(name):
+    got = po.load(os.path.join(DATA, name), isTrans=False, mode=0)
+    assert bit_equal(got, unpack(FX, name.replace(".", "_") + "_load"))
+
+
+def test_loader_empty_input():
+    # tdata.snap has no size line: parsed as rows=0 nnz=0 (COO.cc:80-89); must not crash
+    got = po.load(os.path.join(DATA, "tdata.snap"))
+    assert got.rows == 0 and got.nnz == 0 and list(got.rowPtr) == [0]
+
+
+@pytest.mark.parametrize("name", SQUARE)
+def test_sequential_spmm_bit_exact(name):
+    key = name.replace(".", "_")
+    A = unpack(FX, key + "_load")
+    want = unpack(FX, key + "_AA")
+    assert bit_equal(po.sequential_spmm(A, A), want)       # first-touch order + float bits
+    assert bit_equal(po.omp_spmm(A, A), want)              # the parallel restatement agrees too
+
+
+@pytest.mark.parametrize("name", SQUARE)
+@pytest.mark.parametrize("trans", [0, 1])
+def test_rmcl_init(name, trans):
+    got = po.load(os.path.join(DATA, name), isTrans=bool(trans), mode=1)
+    assert bit_equal(got, unpack(FX, f"{name.replace('.', '_')}_init_t{trans}"))
+
+
+@pytest.mark.parametrize("name", SQUARE)
+@pytest.mark.parametrize("iters", [1, 2, 3])
+def test_rmcl_iterations_bit_exact(name, iters):
+    Mt = po.load(os.path.join(DATA, name), isTrans=True, mode=1)     # RMCL() reads the transpose (qrmcl.cc:138)
+    got = po.rmcl_iters(Mt, Mt, iters)
+    assert bit_equal(got, unpack(FX, f"{name.replace('.', '_')}_rmcl{iters}"))
+
+
+def test_known_answers_from_survey():
+    ka = META["survey_known_answers"]
+    A = po.load(os.path.join(DATA, "test2.mtx"))
+    Cm = po.sequential_spmm(A, A)
+    assert list(Cm.rowPtr) == ka["test2_mtx_AA_rowPtr"]
+    for i in range(4):
+        row = [(int(c), float(v)) for c, v in zip(Cm.colInd[Cm.rowPtr[i]:Cm.rowPtr[i + 1]], Cm.values[Cm.rowPtr[i]:Cm.rowPtr[i + 1]])]
+        want = [(int(c), float(v)) for c, v in ka[f"test2_mtx_AA_row{i}"]]
+        assert [c for c, _ in row] == [c for c, _ in want]
+        assert np.allclose([v for _, v in row], [v for _, v in want], rtol=1e-6)
+    Mt = po.load(os.path.join(DATA, "t2.snap"), isTrans=True, mode=1)
+    R = po.rmcl_iters(Mt, Mt, 3)
+    trip = [[i, int(R.colInd[j]), float(R.values[j])] for i in range(R.rows) for j in range(R.rowPtr[i], R.rowPtr[i + 1])]
+    assert trip == ka["t2_snap_rmcl3"]
+
+
+@pytest.mark.parametrize("key", ["synth_64_3_2", "synth_512_7_2", "synth_1024_9_4"])
+def test_synth_small_bit_exact(key):
+    _, m, seed, base = key.split("_")
+    A = synth_csr(int(m), int(seed), int(base))
+    want = unpack(SM, key + "_AA")
+    assert bit_equal(po.sequential_spmm(A, A), want)
+    assert bit_equal(po.omp_spmm(A, A), want)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_rectangular_unsorted_bit_exact(idx):
+    A, B, want = unpack(SM, f"rect{idx}_A"), unpack(SM, f"rect{idx}_B"), unpack(SM, f"rect{idx}_C")
+    assert bit_equal(po.sequential_spmm(A, B), want)
+    assert bit_equal(po.omp_spmm(A, B), want)
+
+
+@pytest.mark.parametrize("key", ["4096_11_2", "32768_13_2", "65536_17_4"])
+def test_synth_summaries(key):
+    g = META["synth"][key]
+    A = synth_csr(g["m"], g["seed"], g["base"])
+    assert A.nnz == g["nnzA"]
+    f = po.row_flops(A, A)
+    assert int(f.sum()) == g["P"] and int(f.max()) == g["max_row_flops"]
+    rf, groups, tops = po.group_bins(A, A)
+    assert [int(x) for x in tops] == g["group_tops"]
+    pref = np.concatenate([[0], np.cumsum(f)])
+    assert [int(x) for x in po.equal_partition64(pref, 8)] == g["partition8"]
+    s = summarize(po.omp_spmm(A, A))
+    assert s["nnz"] == g["nnz"] and s["hash"] == g["hash"]
+    assert abs(s["sum"] - g["sum"]) <= 1e-9 * abs(g["sum"]) and abs(s["wsum"] - g["wsum"]) <= 1e-9 * abs(g["wsum"])
+
+
+def test_headline_instance_numbers():
+    """seed 42, m=262144, base 2 -> nnzA=3 887 048, P=58 865 303 (generator pin)."""
+    ka = META["survey_known_answers"]["synth_262144_42_2"]
+    A = synth_csr(262144, 42, 2)
+    assert A.nnz == ka["nnzA"]
+    assert int(po.row_flops(A, A).sum()) == ka["P"]
+    assert META["synth"]["262144_42_2"]["nnz"] == ka["nnzC"]
+
+
+def test_gpu_bin_ids_and_classify():
+    # dqueueId edges (mindex2-cuda/flops.cu:39-47)
+    L = po.lib()
+    want = {0: 1, 1: 2, 2: 3, 4: 3, 5: 4, 16: 4, 17: 5, 64: 5, 65: 6, 512: 6, 513: 7, 10**9: 7}
+    for x, b in want.items():
+        assert L.oracle_gpu_bin_id(x) == b
+    flops = np.array([5, 0, 1, 700, 3, 3, 64, 65, 0, 17], dtype=np.int64)
+    rowIds, scan, hv, n = po.gpu_classify(flops)
+    assert list(rowIds) == [1, 8, 2, 4, 5, 0, 9, 6, 7, 3]          # stable ascending by flops
+    assert list(scan) == [0, 0, 0, 1, 4, 7, 12, 29, 93, 158, 858]
+    # bins incl. the dummy 0-flops element: bin1:{dummy,1,8} bin2:{2} bin3:{4,5} bin4:{0} bin5:{9,6} bin6:{7} bin7:{3}
+    assert list(hv) == [0, 0, 3, 4, 6, 7, 9, 10, 11] and n == 9
+
+
+def test_threshold_math():
+    L = po.lib()
+    assert L.oracle_compute_threshold(0.25, 0.5) == np.float32(0.90 * np.float32(0.25) * (1 - 2 * np.float32(0.25)))
+    assert L.oracle_compute_threshold(0.0, 0.0) == 0.0          # clamps to max
+    assert abs(L.oracle_compute_threshold(1e-9, 1.0) - 1e-7) < 1e-12

@@ -1,0 +1,63 @@
+"""CPU, build container only: the restatement (oracle/oracle.c) against the real reference
+compiled into oracle/_ref/libref.so, on seeded inputs incl. edge cases.  Skipped where _ref is absent."""
+import numpy as np
+import pytest
+
+from helpers import po, random_csr, synth_csr
+from test_oracle_golden import bit_equal
+
+pytestmark = pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref/libref.so not built (no /root/reference here)")
+
+
+@pytest.mark.parametrize("m,seed,base", [(256, 1, 2), (2048, 5, 2), (3000, 6, 4)])
+def test_all_reference_variants_agree_with_restatement(m, seed, base):
+    A = synth_csr(m, seed, base)
+    mine = po.sequential_spmm(A, A)
+    for which in ("sequential", "omp", "static_omp", "flops_omp", "group", "noindex_somp"):
+        assert bit_equal(po.ref_spmm(A, A, which), mine), which
+    assert bit_equal(po.omp_spmm(A, A, stride=7), mine)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_rectangular_random(seed):
+    rng = np.random.default_rng(seed)
+    r, k, c = (int(x) for x in rng.integers(1, 120, size=3))
+    A = random_csr(r, k, float(rng.uniform(0.0, 0.3)), seed, sorted_rows=False)
+    B = random_csr(k, c, float(rng.uniform(0.0, 0.3)), seed + 50, sorted_rows=False)
+    assert bit_equal(po.sequential_spmm(A, B), po.ref_spmm(A, B, "sequential"))
+    assert bit_equal(po.omp_spmm(A, B), po.ref_spmm(A, B, "omp"))
+
+
+def test_empty_rows_and_empty_matrix():
+    A = random_csr(40, 40, 0.0, 1)
+    assert po.sequential_spmm(A, A).nnz == 0 and po.ref_spmm(A, A, "sequential").nnz == 0
+    A = random_csr(50, 50, 0.03, 2)         # many empty rows
+    assert bit_equal(po.sequential_spmm(A, A), po.ref_spmm(A, A, "sequential"))
+
+
+def test_flops_prefix_and_partition():
+    A = synth_csr(5000, 21, 2)
+    pref = po.ref_row_flops_prefix(A, A)
+    f = po.row_flops(A, A)
+    assert np.array_equal(np.concatenate([[0], np.cumsum(f)]), pref)
+    for parts in (1, 2, 3, 4, 8, 64):
+        assert np.array_equal(po.equal_partition64(pref, parts), po.ref_equal_partition64(pref, parts))
+    # degenerate: everything in one row
+    pref2 = np.array([0, 0, 100, 100, 100], dtype=np.int64)
+    for parts in (2, 4):
+        assert np.array_equal(po.equal_partition64(pref2, parts), po.ref_equal_partition64(pref2, parts))
+
+
+def test_group_bins():
+    A = synth_csr(3000, 8, 2)
+    a, b = po.group_bins(A, A), po.ref_group_bins(A, A)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_threshold_random():
+    rng = np.random.default_rng(0)
+    L, R = po.lib(), po.ref()
+    for _ in range(2000):
+        avg, mx = np.float32(rng.random()), np.float32(rng.random())
+        assert L.oracle_compute_threshold(avg, mx) == R.ref_compute_threshold(avg, mx)
