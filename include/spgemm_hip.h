@@ -1,0 +1,168 @@
+/* include/spgemm_hip.h — C ABI of libspgemm_hip.so: the MI355X (gfx950) CSR x CSR SpGEMM hot path.
+ *
+ * This is the drop-in boundary for the reference's SpGEMM kernel call surface.  Every entry point is
+ * extern "C", takes plain pointers and sizes (int32 indices, float32 values — QValue is float,
+ * nlibs/tools/macro.h:5; indices are int, nlibs/CSR.h:32-38) and returns an int status (0 = ok);
+ * nothing throws across this boundary.  The C++ mirror of the reference's CSR/COO types and wrapper
+ * functions (sparse_matrix_with_flops_amd/csrc/nlibs) sits on top of it and keeps the reference's
+ * exit-on-error convention (nlibs/gpus/cuda_handle_error.h:7-15).
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the reference tree).
+ * Thread model: one caller thread per handle; calls return after the device work has completed
+ * (the reference's GPU path is blocking too: nlibs/gpus/gpu_csr_kernel.cu:162).
+ */
+#ifndef SPGEMM_HIP_H_
+#define SPGEMM_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ---------------------------------------------------------------------------- */
+#define SPGEMM_OK                0
+#define SPGEMM_ERR_HIP           1   /* a HIP runtime call failed (see spgemm_hip_last_error)         */
+#define SPGEMM_ERR_ARG           2   /* bad argument: null pointer, negative size, shape mismatch     */
+#define SPGEMM_ERR_OVERFLOW      3   /* nnz(C) does not fit the int32 CSR the boundary mandates       */
+#define SPGEMM_ERR_NOMEM         4   /* host malloc failed                                            */
+#define SPGEMM_ERR_INPUT         5   /* host CSR failed validation (rowPtr not monotone, col range)   */
+#define SPGEMM_ERR_INTERNAL      6   /* device-side invariant broken (hash table full, count mismatch)*/
+#define SPGEMM_ERR_NODEVICE      7   /* no HIP device: the product path has NO CPU fallback           */
+
+/* internal row bins by intermediate-product count ("flops") */
+#define SPGEMM_NBINS             8
+/* reference-visible bin boundaries: hv[] as returned by gpuFlopsClassify (mindex2-cuda/flops.cu:96-107) */
+#define SPGEMM_HV_LEN            9
+#define SPGEMM_NKERNELS          16
+
+typedef struct spgemm_handle spgemm_handle;
+
+/* per-call statistics (filled by every SpGEMM entry point that takes a handle) */
+typedef struct spgemm_stats {
+  long long total_flops;          /* P = sum over A nonzeros of nnz(B row): "intermediate_nnz"           */
+  int       nnzC;
+  int       bin_rows[SPGEMM_NBINS];/* rows per internal bin {0 | 1 | 2-4 | 5-16 | 17-64 | 65-512 | 513-4096 | >4096} */
+  float     ms_classify;          /* HIP-event times on the handle's stream                              */
+  float     ms_symbolic;
+  float     ms_scan_alloc;
+  float     ms_numeric;
+  float     ms_total;
+  float     ms_kernel[SPGEMM_NKERNELS]; /* HIP-event duration of every launch of the last call (0 = not launched);
+                                     index = SPGEMM_K_* below                                          */
+} spgemm_stats;
+
+/* kernel ids for spgemm_stats.ms_kernel / spgemm_hip_kernel_name */
+enum {
+  SPGEMM_K_ROW_FLOPS = 0, SPGEMM_K_BIN_SCAN, SPGEMM_K_SCATTER,
+  SPGEMM_K_SYM_SMALL4, SPGEMM_K_SYM_SMALL8, SPGEMM_K_SYM_HASH1, SPGEMM_K_SYM_HASH8, SPGEMM_K_SYM_BIG,
+  SPGEMM_K_SCAN,
+  SPGEMM_K_NUM_SMALL4, SPGEMM_K_NUM_SMALL8, SPGEMM_K_NUM_HASH1, SPGEMM_K_NUM_HASH8, SPGEMM_K_NUM_BIG
+};
+const char* spgemm_hip_kernel_name(int id);
+
+/* ---- library / device ------------------------------------------------------------------------ */
+const char* spgemm_hip_last_error(void);          /* thread-local message of the last failure          */
+int  spgemm_hip_device_count(int* count);
+int  spgemm_hip_create(spgemm_handle** h, int device);   /* hipSetDevice(device), stream, workspace   */
+int  spgemm_hip_destroy(spgemm_handle* h);
+int  spgemm_hip_get_stats(const spgemm_handle* h, spgemm_stats* out);
+void* spgemm_hip_stream(spgemm_handle* h);        /* hipStream_t the kernels run on (for event timing) */
+
+/* ---- device memory: replaces the cudaMalloc/cudaMemcpy/cudaFree inside
+ *      CSR::toGpuCSR / toCpuCSR / deviceDispose  (nlibs/CSR.cc:342-379) ------------------------- */
+int  spgemm_hip_malloc(void** dptr, size_t bytes);
+int  spgemm_hip_free(void* dptr);
+int  spgemm_hip_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int  spgemm_hip_memcpy_d2h(void* dst, const void* src, size_t bytes);
+
+/* ---- (1) host arrays in, host arrays out ------------------------------------------------------
+ * Replaces the *_CSR_SpMM family:  sequential_CSR_SpMM / omp_CSR_SpMM / static_omp_CSR_SpMM /
+ * flops_omp_CSR_SpMM / group_CSR_SpMM  (nlibs/cpu_csr_kernel.h:63-102), called from the CSR::*spmm
+ * one-liners (nlibs/CSR.cc:59-208); also scudaSpMM(hA,hB) (mindex2-cuda/nGpuSpMM.cc:245-279).
+ * A is m x k, B is k x n.  Inputs are borrowed.  *IC (m+1), *JC (nnzC), *C (nnzC) are malloc()ed here
+ * so the caller's CSR::dispose() == free() stays valid (nlibs/CSR.h:323-327).
+ * Rows of C are not column-sorted (same contract as the reference: nlibs/CSR.cc:73-86 exists for that). */
+int hip_CSR_SpMM(const int* IA, const int* JA, const float* A, int nnzA,
+                 const int* IB, const int* JB, const float* B, int nnzB,
+                 int** IC, int** JC, float** C, int* nnzC,
+                 int m, int k, int n);
+
+/* ---- (2) device-resident in, device-resident out ----------------------------------------------
+ * Replaces CSR gpuSpMMWrapper(const CSR& dA, const CSR& dB)  (nlibs/gpus/gpu_csr_kernel.h:6,
+ * gpu_csr_kernel.cu:128-173).  All d* pointers are device memory.  *dIC (m+1), *dJC, *dC are
+ * allocated here (release with spgemm_hip_free == CSR::deviceDispose).  h may be NULL (a private
+ * per-process handle on device 0 is used, like the reference's implicit device 0). */
+int hip_gpuSpMM(spgemm_handle* h,
+                const int* dIA, const int* dJA, const float* dA, int nnzA,
+                const int* dIB, const int* dJB, const float* dB, int nnzB,
+                int m, int k, int n,
+                int** dIC, int** dJC, float** dC, int* nnzC);
+
+/* ---- (2b) the same in two phases, outputs owned by the caller ----------------------------------
+ * The reference's complete binned path is two-phase as well: gpu_compute_IC (symbolic, per bin) ->
+ * exclusive scan -> cudaMalloc JC,C -> sgpu_SpGEMM (numeric, per bin)  ("mindex2-cuda/\":524-555, :322-483).
+ * hip_spgemm_symbolic fills dIC[m+1] (caller-allocated device ints) with C's rowPtr and returns nnzC;
+ * the handle keeps the row classification.  hip_spgemm_numeric must follow on the same handle with the
+ * same A, B and dIC; it writes dJC[nnzC], dC[nnzC] (caller-allocated, e.g. a slice of a gathered
+ * multi-GPU buffer).  h must not be NULL. */
+int hip_spgemm_symbolic(spgemm_handle* h,
+                        const int* dIA, const int* dJA, int nnzA,
+                        const int* dIB, const int* dJB, int nnzB,
+                        int m, int k, int n, int* dIC, int* nnzC);
+int hip_spgemm_numeric(spgemm_handle* h,
+                       const int* dIA, const int* dJA, const float* dA, int nnzA,
+                       const int* dIB, const int* dJB, const float* dB, int nnzB,
+                       int m, int k, int n, const int* dIC, int* dJC, float* dC);
+
+/* per-row product counts only (gcomputeFlops, mindex2-cuda/flops.cu:66-83; dynamic_omp_CSR_flops,
+ * nlibs/flops_csr_kernel.cc:14-31): dRowFlops[m] device ints (saturating at INT_MAX), *total_flops = P.
+ * Feeds the flops-balanced row partition (arrayEqualPartition64, nlibs/tools/util.cc:123-135). */
+int hip_csr_row_flops(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, int m,
+                      int* dRowFlops, long long* total_flops);
+
+/* ---- (3) per-row flop count + row binning ------------------------------------------------------
+ * Replaces std::vector<int> gpuFlopsClassify(const CSR& dA, const CSR& dB, int** drowIdsp,
+ * int** dflopId)  (mindex2-cuda/flops.cu:110-185; kernels gcomputeFlops :66-83, gcomputeBinId :87-94).
+ *   *drowIds   device int[m]   : row ids grouped by bin, bins ascending; inside a bin rows ascend
+ *                                (the reference sorts fully by flops with thrust::stable_sort_by_key;
+ *                                 no consumer depends on the order inside a bin)
+ *   *dflops    device int[m+1] : dflops[0]=0, dflops[1+q] = inclusive scan of the flops of
+ *                                drowIds[0..q] (saturating at INT_MAX)        (flops.cu:119,133)
+ *   hv[9]      host            : hv[0]=0, hv[b+1] = number of elements with reference bin id <= b in the
+ *                                (m+1)-long array {dummy 0-flop element, rows...}; reference bin ids
+ *                                (dqueueId, flops.cu:39-47): 0->1, 1->2, 2..4->3, 5..16->4, 17..64->5,
+ *                                65..512->6, >512->7.   Callers index rows of bin b as
+ *                                drowIds + hv[b] - 1  (mindex2-cuda/gnnz.cuh:27).
+ *   *hv_len                    : number of entries the reference's vector would have (max bin + 2)
+ *   *total_flops               : P (64-bit; the reference's int scan overflows at 2^31)
+ * drowIds/dflops are released by the caller with spgemm_hip_free (nGpuSpMM.cc:271). */
+int hip_gpuFlopsClassify(spgemm_handle* h,
+                         const int* dIA, const int* dJA, const int* dIB,
+                         int m, int k,
+                         int** drowIds, int** dflops, int hv[SPGEMM_HV_LEN], int* hv_len,
+                         long long* total_flops);
+
+/* ---- (4) binned SpGEMM on a given classification ----------------------------------------------
+ * Replaces CSR sgpuSpMMWrapper(const CSR& dA, const CSR& dB, int* drowIds, const vector<int>& hv,
+ * int* dflops)  (mindex2-cuda/kernel.cu:311-427; HEAD returns an empty CSR, the complete older
+ * version is the file "mindex2-cuda/\":485-565).  drowIds/hv must come from hip_gpuFlopsClassify for
+ * the same A,B.  Outputs as in (2). */
+int hip_sgpuSpMM(spgemm_handle* h,
+                 const int* dIA, const int* dJA, const float* dA, int nnzA,
+                 const int* dIB, const int* dJB, const float* dB, int nnzB,
+                 int m, int k, int n,
+                 const int* drowIds, const int hv[SPGEMM_HV_LEN], const int* dflops,
+                 int** dIC, int** dJC, float** dC, int* nnzC);
+
+/* ---- helpers the reference's drivers use around the path --------------------------------------- */
+/* CSR::makeOrdered on device arrays (nlibs/CSR.cc:73-86): sort every row by column, in place. */
+int hip_csr_sort_rows(spgemm_handle* h, int m, const int* dIC, int* dJC, float* dC);
+
+/* device self-test of the wave/block primitives (scans, ballots); returns SPGEMM_OK or INTERNAL */
+int spgemm_hip_selftest(spgemm_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPGEMM_HIP_H_ */

@@ -1,0 +1,739 @@
+// spgemm_hip.hip — host side of libspgemm_hip.so: the extern "C" boundary declared in
+// include/spgemm_hip.h, the workspace/handle, and the launch sequence of the kernels in
+// spgemm_device.hpp.  gfx950 only.  There is NO CPU fallback in this library: without a HIP device
+// every entry point fails with SPGEMM_ERR_NODEVICE / SPGEMM_ERR_HIP.
+#include "spgemm_device.hpp"
+#include "../../include/spgemm_hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+using namespace smf;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPCHK(expr)                                                                               \
+  do {                                                                                             \
+    hipError_t e__ = (expr);                                                                       \
+    if (e__ != hipSuccess)                                                                         \
+      return fail(SPGEMM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+#define CHK(expr)                                                                                  \
+  do {                                                                                             \
+    int rc__ = (expr);                                                                             \
+    if (rc__ != SPGEMM_OK) return rc__;                                                            \
+  } while (0)
+
+extern "C" const char* spgemm_hip_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// caching device allocator behind spgemm_hip_malloc/free (the role cudaMalloc/cudaFree play in
+// CSR::toGpuCSR/deviceDispose, nlibs/CSR.cc:342-379).  Freed blocks are kept (bounded) and reused,
+// so the per-call allocation of C costs a map lookup in steady state instead of a hipMalloc.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct DevPool {
+  std::mutex mu;
+  std::map<void*, size_t> live;                 // ptr -> rounded size
+  std::multimap<size_t, void*> free_blocks;     // rounded size -> ptr
+  size_t cached_bytes = 0;
+  static constexpr size_t kMaxCached = size_t(64) << 30;   // 64 GiB of 288 GiB HBM
+  static size_t round_up(size_t b) {
+    if (b < 512) b = 512;
+    if (b <= (size_t(1) << 20)) return (b + 511) & ~size_t(511);
+    const size_t g = size_t(2) << 20;            // 2 MiB granules for big blocks
+    return (b + g - 1) / g * g;
+  }
+  hipError_t alloc(void** p, size_t bytes) {
+    const size_t r = round_up(bytes);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = free_blocks.lower_bound(r);
+      if (it != free_blocks.end() && it->first <= r + r / 4 + (size_t(2) << 20)) {
+        *p = it->second;
+        live[*p] = it->first;
+        cached_bytes -= it->first;
+        free_blocks.erase(it);
+        return hipSuccess;
+      }
+    }
+    hipError_t e = hipMalloc(p, r);
+    if (e != hipSuccess) {                       // give cached memory back and retry once
+      trim();
+      e = hipMalloc(p, r);
+    }
+    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu); live[*p] = r; }
+    return e;
+  }
+  hipError_t release(void* p) {
+    if (!p) return hipSuccess;
+    size_t sz = 0;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = live.find(p);
+      if (it == live.end()) return hipFree(p);   // not ours: plain hipFree
+      sz = it->second;
+      live.erase(it);
+      if (cached_bytes + sz <= kMaxCached) {
+        free_blocks.emplace(sz, p);
+        cached_bytes += sz;
+        return hipSuccess;
+      }
+    }
+    return hipFree(p);
+  }
+  void trim() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& kv : free_blocks) (void)hipFree(kv.second);
+    free_blocks.clear();
+    cached_bytes = 0;
+  }
+};
+DevPool& pool() { static DevPool* p = new DevPool(); return *p; }
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// handle / workspace
+// ------------------------------------------------------------------------------------------------
+struct HostMirror {                 // pinned; filled by one async copy batch per call
+  int binPtr[NBINS + 1];
+  int err;
+  int pad;
+  unsigned long long totalP;
+  unsigned long long nnzC64;
+};
+
+struct spgemm_handle {
+  int device = 0;
+  int numCU = 256;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // device workspace, sized for cap_m rows
+  int cap_m = -1;
+  int* rowFlops = nullptr;
+  unsigned char* binId = nullptr;
+  int* blockHist = nullptr;
+  int* blockOff = nullptr;
+  int* rowIds = nullptr;
+  unsigned long long* tileSum = nullptr;
+  // small fixed device block: binPtr[NBINS+1] | err | pad | totalP | nnzC64   (same layout as HostMirror)
+  HostMirror* dsmall = nullptr;
+  HostMirror* hsmall = nullptr;
+  HostMirror mirror;                 // host copy taken at the end of the symbolic phase
+  const int* cur_rowIds = nullptr;   // row list of the pending symbolic phase (workspace or caller's)
+  int sym_m = -1;                    // rows of the pending symbolic phase, -1 = none
+  hipEvent_t kev[2 * SPGEMM_NKERNELS];
+  bool kused[SPGEMM_NKERNELS];
+  spgemm_stats stats;
+};
+
+static int ws_free(spgemm_handle* h) {
+  hipFree(h->rowFlops); hipFree(h->binId); hipFree(h->blockHist); hipFree(h->blockOff);
+  hipFree(h->rowIds); hipFree(h->tileSum);
+  h->rowFlops = nullptr; h->binId = nullptr; h->blockHist = nullptr; h->blockOff = nullptr;
+  h->rowIds = nullptr; h->tileSum = nullptr; h->cap_m = -1;
+  return SPGEMM_OK;
+}
+
+static int ws_ensure(spgemm_handle* h, int m) {
+  if (m <= h->cap_m) return SPGEMM_OK;
+  ws_free(h);
+  const size_t cap = (size_t)m + (size_t)m / 8 + 1024;
+  const size_t nblk = (cap + K1_THREADS - 1) / K1_THREADS;
+  const size_t ntile = (cap + 1 + SCAN_TILE - 1) / SCAN_TILE + 1;
+  HIPCHK(hipMalloc((void**)&h->rowFlops, sizeof(int) * cap));
+  HIPCHK(hipMalloc((void**)&h->binId, cap));
+  HIPCHK(hipMalloc((void**)&h->blockHist, sizeof(int) * nblk * NBINS));
+  HIPCHK(hipMalloc((void**)&h->blockOff, sizeof(int) * nblk * NBINS));
+  HIPCHK(hipMalloc((void**)&h->rowIds, sizeof(int) * cap));
+  HIPCHK(hipMalloc((void**)&h->tileSum, sizeof(unsigned long long) * ntile));
+  h->cap_m = (int)std::min<size_t>(cap, 0x7fffffff);
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_hip_device_count(int* count) {
+  if (!count) return fail(SPGEMM_ERR_ARG, "count is null");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return fail(SPGEMM_ERR_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+  *count = n;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_hip_create(spgemm_handle** out, int device) {
+  if (!out) return fail(SPGEMM_ERR_ARG, "handle out-pointer is null");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(SPGEMM_ERR_NODEVICE, "no HIP device visible: libspgemm_hip has no CPU fallback");
+  if (device < 0 || device >= n) return fail(SPGEMM_ERR_ARG, "device %d out of range [0,%d)", device, n);
+  HIPCHK(hipSetDevice(device));
+  spgemm_handle* h = new spgemm_handle();
+  h->device = device;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  h->numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  for (auto& e : h->ev) HIPCHK(hipEventCreate(&e));
+  for (auto& e : h->kev) HIPCHK(hipEventCreate(&e));
+  for (auto& u : h->kused) u = false;
+  HIPCHK(hipMalloc((void**)&h->dsmall, sizeof(HostMirror)));
+  HIPCHK(hipHostMalloc((void**)&h->hsmall, sizeof(HostMirror), hipHostMallocDefault));
+  memset(&h->stats, 0, sizeof(h->stats));
+  // the big-row kernels use more than the default 64 KB of dynamic LDS
+  HIPCHK(hipFuncSetAttribute((const void*)k_sym_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigSymShared)));
+  HIPCHK(hipFuncSetAttribute((const void*)k_num_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigNumShared)));
+  *out = h;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_hip_destroy(spgemm_handle* h) {
+  if (!h) return SPGEMM_OK;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  ws_free(h);
+  hipFree(h->dsmall);
+  hipHostFree(h->hsmall);
+  for (auto& e : h->ev) if (e) hipEventDestroy(e);
+  for (auto& e : h->kev) if (e) hipEventDestroy(e);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_hip_get_stats(const spgemm_handle* h, spgemm_stats* out) {
+  if (!h || !out) return fail(SPGEMM_ERR_ARG, "null argument");
+  *out = h->stats;
+  return SPGEMM_OK;
+}
+
+extern "C" void* spgemm_hip_stream(spgemm_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+static std::mutex g_default_mu;
+static spgemm_handle* g_default = nullptr;
+static int default_handle(spgemm_handle** out) {
+  std::lock_guard<std::mutex> lk(g_default_mu);
+  if (!g_default) CHK(spgemm_hip_create(&g_default, 0));
+  *out = g_default;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_hip_malloc(void** dptr, size_t bytes) {
+  if (!dptr) return fail(SPGEMM_ERR_ARG, "dptr is null");
+  *dptr = nullptr;
+  HIPCHK(pool().alloc(dptr, bytes ? bytes : 1));
+  return SPGEMM_OK;
+}
+extern "C" int spgemm_hip_free(void* dptr) {
+  HIPCHK(pool().release(dptr));
+  return SPGEMM_OK;
+}
+extern "C" int spgemm_hip_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+  if (bytes && (!dst || !src)) return fail(SPGEMM_ERR_ARG, "null pointer in h2d copy");
+  if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return SPGEMM_OK;
+}
+extern "C" int spgemm_hip_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+  if (bytes && (!dst || !src)) return fail(SPGEMM_ERR_ARG, "null pointer in d2h copy");
+  if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return SPGEMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch sequence
+// ------------------------------------------------------------------------------------------------
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline int clampi(long long v, int lo, int hi) { return (int)std::max<long long>(lo, std::min<long long>(v, hi)); }
+
+static const char* kKernelNames[SPGEMM_NKERNELS] = {
+    "k_row_flops", "k_bin_scan", "k_scatter_rows", "k_sym_small<4,32>", "k_sym_small<8,128>", "k_sym_hash<1,1024>",
+    "k_sym_hash<8,8192>", "k_sym_big", "k_scan(3 launches)", "k_num_small<4,32>", "k_num_small<8,128>",
+    "k_num_hash<1,1024>", "k_num_hash<8,8192>", "k_num_big", "", ""};
+extern "C" const char* spgemm_hip_kernel_name(int id) { return (id >= 0 && id < SPGEMM_NKERNELS) ? kKernelNames[id] : ""; }
+
+// every launch is bracketed by two events on the handle's stream (per-kernel durations for bench.py's roofline)
+struct KTimer {
+  spgemm_handle* h; int id;
+  KTimer(spgemm_handle* h_, int id_) : h(h_), id(id_) { hipEventRecord(h->kev[2 * id], h->stream); h->kused[id] = true; }
+  ~KTimer() { hipEventRecord(h->kev[2 * id + 1], h->stream); }
+};
+
+static void collect_kernel_times(spgemm_handle* h, bool reset) {
+  for (int i = 0; i < SPGEMM_NKERNELS; ++i) {
+    if (reset) h->stats.ms_kernel[i] = 0.f;
+    if (h->kused[i]) { float ms = 0.f; if (hipEventElapsedTime(&ms, h->kev[2 * i], h->kev[2 * i + 1]) == hipSuccess) h->stats.ms_kernel[i] = ms; }
+    h->kused[i] = false;
+  }
+}
+
+// flops + bins: K1, K2, K3.  Also presets IC[row] for rows with 0 / 1 products.
+static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, int m, int* dIC) {
+  const int nblk = cdiv(m, K1_THREADS);
+  HIPCHK(hipMemsetAsync(h->dsmall, 0, sizeof(HostMirror), h->stream));
+  if (m > 0) {
+    { KTimer t(h, SPGEMM_K_ROW_FLOPS);
+      hipLaunchKernelGGL(k_row_flops, dim3(nblk), dim3(K1_THREADS), 0, h->stream, m, dIA, dJA, dIB, h->rowFlops,
+                         h->binId, h->blockHist, &h->dsmall->totalP, dIC); }
+    { KTimer t(h, SPGEMM_K_BIN_SCAN);
+      hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, h->stream, nblk, h->blockHist, h->blockOff,
+                         h->dsmall->binPtr); }
+    { KTimer t(h, SPGEMM_K_SCATTER);
+      hipLaunchKernelGGL(k_scatter_rows, dim3(nblk), dim3(K1_THREADS), 0, h->stream, m, h->binId, h->blockOff,
+                         h->rowIds); }
+  }
+  HIPCHK(hipGetLastError());
+  return SPGEMM_OK;
+}
+
+// symbolic pass over bins 2..7 (bins 0/1 were preset by K1).  Bin sizes are not known on the host
+// here (no sync): grids are capped by the CU count and every block strides over its bin.
+static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, const int* dJB,
+                           int m, int n, const int* rowIds, int* dIC) {
+  if (m <= 0) return SPGEMM_OK;
+  const int* bp = h->dsmall->binPtr;
+  int* err = &h->dsmall->err;
+  const int cu = h->numCU;
+  { KTimer t(h, SPGEMM_K_SYM_SMALL4);
+    hipLaunchKernelGGL((k_sym_small<4, 32>), dim3(clampi(cdiv(m, 64), 1, cu * 8)), dim3(256), 0, h->stream, bp, 2, 4,
+                       rowIds, dIA, dJA, dIB, dJB, h->rowFlops, dIC, err); }
+  { KTimer t(h, SPGEMM_K_SYM_SMALL8);
+    hipLaunchKernelGGL((k_sym_small<8, 128>), dim3(clampi(cdiv(m, 32), 1, cu * 8)), dim3(256), 0, h->stream, bp, 4, 5,
+                       rowIds, dIA, dJA, dIB, dJB, h->rowFlops, dIC, err); }
+  { KTimer t(h, SPGEMM_K_SYM_HASH1);
+    hipLaunchKernelGGL((k_sym_hash<1, 1024>), dim3(clampi(m, 1, cu * 24)), dim3(64), 0, h->stream, bp, 5, rowIds, dIA,
+                       dJA, dIB, dJB, h->rowFlops, dIC, err); }
+  { KTimer t(h, SPGEMM_K_SYM_HASH8);
+    hipLaunchKernelGGL((k_sym_hash<8, 8192>), dim3(clampi(m, 1, cu * 3)), dim3(512), 0, h->stream, bp, 6, rowIds, dIA,
+                       dJA, dIB, dJB, h->rowFlops, dIC, err); }
+  { KTimer t(h, SPGEMM_K_SYM_BIG);
+    hipLaunchKernelGGL(k_sym_big, dim3(clampi(m, 1, cu * 2)), dim3(BIG_THREADS), sizeof(BigSymShared), h->stream, bp, 7,
+                       rowIds, dIA, dJA, dIB, dJB, n, dIC); }
+  HIPCHK(hipGetLastError());
+  return SPGEMM_OK;
+}
+
+// exclusive scan of cnt[0..m) in place, cnt[m] = total; 64-bit total lands in *dTotal
+static int launch_scan(spgemm_handle* h, int* cnt, int m, unsigned long long* dTotal) {
+  const int ntiles = std::max(1, cdiv(m, SCAN_TILE));
+  KTimer t(h, SPGEMM_K_SCAN);
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(SCAN_THREADS), 0, h->stream, m, cnt, h->tileSum);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, h->stream, ntiles, h->tileSum, dTotal);
+  hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(SCAN_THREADS), 0, h->stream, m, cnt, h->tileSum, dTotal);
+  HIPCHK(hipGetLastError());
+  return SPGEMM_OK;
+}
+
+static int launch_numeric(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, const int* dIB,
+                          const int* dJB, const float* dB, int n, const int* rowIds, const int* hostBinPtr,
+                          const int* dIC, int* dJC, float* dC) {
+  const int* bp = h->dsmall->binPtr;
+  int* err = &h->dsmall->err;
+  const int cu = h->numCU;
+  auto rows = [&](int lo, int hi) { return hostBinPtr[hi] - hostBinPtr[lo]; };
+  if (rows(1, 4) > 0) { KTimer t(h, SPGEMM_K_NUM_SMALL4);
+    hipLaunchKernelGGL((k_num_small<4, 32>), dim3(clampi(cdiv(rows(1, 4), 64), 1, cu * 8)), dim3(256), 0, h->stream, bp,
+                       1, 4, rowIds, dIA, dJA, dA, dIB, dJB, dB, h->rowFlops, dIC, dJC, dC, err); }
+  if (rows(4, 5) > 0) { KTimer t(h, SPGEMM_K_NUM_SMALL8);
+    hipLaunchKernelGGL((k_num_small<8, 128>), dim3(clampi(cdiv(rows(4, 5), 32), 1, cu * 4)), dim3(256), 0, h->stream,
+                       bp, 4, 5, rowIds, dIA, dJA, dA, dIB, dJB, dB, h->rowFlops, dIC, dJC, dC, err); }
+  if (rows(5, 6) > 0) { KTimer t(h, SPGEMM_K_NUM_HASH1);
+    hipLaunchKernelGGL((k_num_hash<1, 1024>), dim3(clampi(rows(5, 6), 1, cu * 12)), dim3(64), 0, h->stream, bp, 5,
+                       rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err); }
+  if (rows(6, 7) > 0) { KTimer t(h, SPGEMM_K_NUM_HASH8);
+    hipLaunchKernelGGL((k_num_hash<8, 8192>), dim3(clampi(rows(6, 7), 1, cu * 2)), dim3(512), 0, h->stream, bp, 6,
+                       rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err); }
+  if (rows(7, 8) > 0) { KTimer t(h, SPGEMM_K_NUM_BIG);
+    hipLaunchKernelGGL(k_num_big, dim3(clampi(rows(7, 8), 1, cu)), dim3(BIG_THREADS), sizeof(BigNumShared), h->stream,
+                       bp, 7, rowIds, dIA, dJA, dA, dIB, dJB, dB, n, dIC, dJC, dC, err); }
+  HIPCHK(hipGetLastError());
+  return SPGEMM_OK;
+}
+
+static int check_common(const void* a, const void* b, const void* c, int nnz, const char* who) {
+  if (nnz < 0) return fail(SPGEMM_ERR_ARG, "%s: negative nnz", who);
+  if (!a) return fail(SPGEMM_ERR_ARG, "%s: rowPtr is null", who);
+  if (nnz > 0 && (!b || !c)) return fail(SPGEMM_ERR_ARG, "%s: colInd/values null with nnz=%d", who, nnz);
+  return SPGEMM_OK;
+}
+
+// `pre` (optional) supplies a classification made earlier by hip_gpuFlopsClassify:
+// row ids grouped by bin + dflops + hv.
+struct PreClass { const int* drowIds; const int* hv; const int* dflops; };
+static int k_unpack_launch(spgemm_handle* h, int m, const PreClass& pre, int* dIC);
+
+// phase 1: classify + symbolic + scan; one host sync at the end (nnzC, bin sizes, error flags)
+static int symbolic_phase(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, const int* dJB,
+                          int m, int k, int n, const PreClass* pre, int* dIC, int* nnzCp) {
+  (void)k;
+  hipStream_t s = h->stream;
+  hipEventRecord(h->ev[0], s);
+  h->cur_rowIds = h->rowIds;
+  if (pre) {
+    CHK(k_unpack_launch(h, m, *pre, dIC));
+    h->cur_rowIds = pre->drowIds;
+  } else {
+    CHK(launch_classify(h, dIA, dJA, dIB, m, dIC));
+  }
+  hipEventRecord(h->ev[1], s);
+  CHK(launch_symbolic(h, dIA, dJA, dIB, dJB, m, n, h->cur_rowIds, dIC));
+  hipEventRecord(h->ev[2], s);
+  if (m > 0) CHK(launch_scan(h, dIC, m, &h->dsmall->nnzC64));
+  else HIPCHK(hipMemsetAsync(dIC, 0, sizeof(int), s));
+  hipEventRecord(h->ev[3], s);
+  if (hipMemcpyAsync(h->hsmall, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return fail(SPGEMM_ERR_HIP, "symbolic phase failed: %s", hipGetErrorString(hipGetLastError()));
+  h->mirror = *h->hsmall;
+  const HostMirror& hm = h->mirror;
+  if (hm.err) return fail(SPGEMM_ERR_INTERNAL, "device invariant broken in symbolic phase (flags=%d)", hm.err);
+  if (hm.nnzC64 > 0x7fffffffULL) return fail(SPGEMM_ERR_OVERFLOW, "nnz(C)=%llu does not fit int32 CSR", hm.nnzC64);
+  spgemm_stats& st = h->stats;
+  st.total_flops = (long long)hm.totalP;
+  st.nnzC = (int)hm.nnzC64;
+  for (int b = 0; b < NBINS; ++b) st.bin_rows[b] = hm.binPtr[b + 1] - hm.binPtr[b];
+  hipEventElapsedTime(&st.ms_classify, h->ev[0], h->ev[1]);
+  hipEventElapsedTime(&st.ms_symbolic, h->ev[1], h->ev[2]);
+  hipEventElapsedTime(&st.ms_scan_alloc, h->ev[2], h->ev[3]);
+  st.ms_numeric = 0.f;
+  st.ms_total = st.ms_classify + st.ms_symbolic + st.ms_scan_alloc;
+  collect_kernel_times(h, true);
+  h->sym_m = m;
+  *nnzCp = (int)hm.nnzC64;
+  return SPGEMM_OK;
+}
+
+// phase 2: numeric into caller-provided dJC/dC; one host sync at the end (error flags)
+static int numeric_phase(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, const int* dIB,
+                         const int* dJB, const float* dB, int m, int n, const int* dIC, int* dJC, float* dC) {
+  if (h->sym_m != m) return fail(SPGEMM_ERR_ARG, "numeric phase without a matching symbolic phase on this handle");
+  hipStream_t s = h->stream;
+  const int nnzC = (int)h->mirror.nnzC64;
+  hipEventRecord(h->ev[4], s);
+  if (m > 0 && nnzC > 0) {
+    if (!dJC || !dC) return fail(SPGEMM_ERR_ARG, "output buffers are null");
+    CHK(launch_numeric(h, dIA, dJA, dA, dIB, dJB, dB, n, h->cur_rowIds, h->mirror.binPtr, dIC, dJC, dC));
+  }
+  hipEventRecord(h->ev[5], s);
+  if (hipMemcpyAsync(&h->hsmall->err, &h->dsmall->err, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return fail(SPGEMM_ERR_HIP, "numeric phase failed: %s", hipGetErrorString(hipGetLastError()));
+  h->sym_m = -1;
+  if (h->hsmall->err) return fail(SPGEMM_ERR_INTERNAL, "device invariant broken in numeric phase (flags=%d)", h->hsmall->err);
+  spgemm_stats& st = h->stats;
+  hipEventElapsedTime(&st.ms_numeric, h->ev[4], h->ev[5]);
+  st.ms_total += st.ms_numeric;
+  collect_kernel_times(h, false);
+  return SPGEMM_OK;
+}
+
+static int spgemm_device(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, int nnzA,
+                         const int* dIB, const int* dJB, const float* dB, int nnzB, int m, int k, int n,
+                         const PreClass* pre, int** dICp, int** dJCp, float** dCp, int* nnzCp) {
+  if (!dICp || !dJCp || !dCp || !nnzCp) return fail(SPGEMM_ERR_ARG, "output pointer is null");
+  *dICp = nullptr; *dJCp = nullptr; *dCp = nullptr; *nnzCp = 0;
+  if (m < 0 || k < 0 || n < 0) return fail(SPGEMM_ERR_ARG, "negative dimension m=%d k=%d n=%d", m, k, n);
+  CHK(check_common(dIA, dJA, dA, nnzA, "A"));
+  CHK(check_common(dIB, dJB, dB, nnzB, "B"));
+  if (!h) CHK(default_handle(&h));
+  HIPCHK(hipSetDevice(h->device));
+  CHK(ws_ensure(h, m));
+  int* dIC = nullptr;
+  int* dJC = nullptr;
+  float* dC = nullptr;
+  auto cleanup = [&](int rc) { pool().release(dIC); pool().release(dJC); pool().release(dC); return rc; };
+  HIPCHK(pool().alloc((void**)&dIC, sizeof(int) * ((size_t)m + 1)));
+  int nnzC = 0;
+  int rc = symbolic_phase(h, dIA, dJA, dIB, dJB, m, k, n, pre, dIC, &nnzC);
+  if (rc) return cleanup(rc);
+  if (hipSuccess != pool().alloc((void**)&dJC, sizeof(int) * (size_t)std::max(nnzC, 1)) ||
+      hipSuccess != pool().alloc((void**)&dC, sizeof(float) * (size_t)std::max(nnzC, 1)))
+    return cleanup(fail(SPGEMM_ERR_HIP, "device allocation of C (%d entries) failed", nnzC));
+  rc = numeric_phase(h, dIA, dJA, dA, dIB, dJB, dB, m, n, dIC, dJC, dC);
+  if (rc) return cleanup(rc);
+  *dICp = dIC; *dJCp = dJC; *dCp = dC; *nnzCp = nnzC;
+  return SPGEMM_OK;
+}
+
+extern "C" int hip_gpuSpMM(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, int nnzA,
+                           const int* dIB, const int* dJB, const float* dB, int nnzB, int m, int k, int n,
+                           int** dIC, int** dJC, float** dC, int* nnzC) {
+  return spgemm_device(h, dIA, dJA, dA, nnzA, dIB, dJB, dB, nnzB, m, k, n, nullptr, dIC, dJC, dC, nnzC);
+}
+
+extern "C" int hip_spgemm_symbolic(spgemm_handle* h, const int* dIA, const int* dJA, int nnzA, const int* dIB,
+                                   const int* dJB, int nnzB, int m, int k, int n, int* dIC, int* nnzC) {
+  if (!h) return fail(SPGEMM_ERR_ARG, "hip_spgemm_symbolic needs a handle");
+  if (!dIC || !nnzC) return fail(SPGEMM_ERR_ARG, "output pointer is null");
+  if (m < 0 || k < 0 || n < 0) return fail(SPGEMM_ERR_ARG, "negative dimension");
+  CHK(check_common(dIA, dJA, dJA, nnzA, "A"));
+  CHK(check_common(dIB, dJB, dJB, nnzB, "B"));
+  HIPCHK(hipSetDevice(h->device));
+  CHK(ws_ensure(h, m));
+  return symbolic_phase(h, dIA, dJA, dIB, dJB, m, k, n, nullptr, dIC, nnzC);
+}
+
+extern "C" int hip_spgemm_numeric(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, int nnzA,
+                                  const int* dIB, const int* dJB, const float* dB, int nnzB, int m, int k, int n,
+                                  const int* dIC, int* dJC, float* dC) {
+  (void)k;
+  if (!h) return fail(SPGEMM_ERR_ARG, "hip_spgemm_numeric needs a handle");
+  if (!dIC) return fail(SPGEMM_ERR_ARG, "dIC is null");
+  CHK(check_common(dIA, dJA, dA, nnzA, "A"));
+  CHK(check_common(dIB, dJB, dB, nnzB, "B"));
+  HIPCHK(hipSetDevice(h->device));
+  return numeric_phase(h, dIA, dJA, dA, dIB, dJB, dB, m, n, dIC, dJC, dC);
+}
+
+extern "C" int hip_csr_row_flops(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, int m,
+                                 int* dRowFlops, long long* total_flops) {
+  if (!h) CHK(default_handle(&h));
+  if (m < 0 || !dIA || (m > 0 && !dRowFlops)) return fail(SPGEMM_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  CHK(ws_ensure(h, m));
+  int* tmpIC = nullptr;
+  HIPCHK(pool().alloc((void**)&tmpIC, sizeof(int) * ((size_t)m + 1)));
+  int rc = launch_classify(h, dIA, dJA, dIB, m, tmpIC);
+  if (rc == SPGEMM_OK && m > 0 &&
+      hipMemcpyAsync(dRowFlops, h->rowFlops, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+    rc = fail(SPGEMM_ERR_HIP, "copy of row flops failed");
+  if (rc == SPGEMM_OK && (hipMemcpyAsync(h->hsmall, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                          hipStreamSynchronize(h->stream) != hipSuccess))
+    rc = fail(SPGEMM_ERR_HIP, "row flops failed: %s", hipGetErrorString(hipGetLastError()));
+  pool().release(tmpIC);
+  if (rc) return rc;
+  collect_kernel_times(h, true);
+  if (total_flops) *total_flops = (long long)h->hsmall->totalP;
+  return SPGEMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// classification API (reference-shaped outputs)
+// ------------------------------------------------------------------------------------------------
+static void hv_from_binptr(const int* binPtr, int m, int hv[SPGEMM_HV_LEN], int* hv_len) {
+  // reference bins (dqueueId): 1:{0} 2:{1} 3:{2..4} 4:{5..16} 5:{17..64} 6:{65..512} 7:{>512}; element 0 of the
+  // (m+1)-long bin array is a dummy with 0 flops (bin 1).
+  int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  cnt[1] = 1 + (binPtr[1] - binPtr[0]);
+  cnt[2] = binPtr[2] - binPtr[1];
+  cnt[3] = binPtr[3] - binPtr[2];
+  cnt[4] = binPtr[4] - binPtr[3];
+  cnt[5] = binPtr[5] - binPtr[4];
+  cnt[6] = binPtr[6] - binPtr[5];
+  cnt[7] = binPtr[8] - binPtr[6];
+  hv[0] = 0;
+  int maxbin = 1;
+  for (int b = 0; b < 8; ++b) { hv[b + 1] = hv[b] + cnt[b]; if (cnt[b] > 0) maxbin = b; }
+  (void)m;
+  *hv_len = maxbin + 2;
+}
+
+extern "C" int hip_gpuFlopsClassify(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, int m, int k,
+                                    int** drowIds, int** dflops, int hv[SPGEMM_HV_LEN], int* hv_len,
+                                    long long* total_flops) {
+  (void)k;
+  if (!drowIds || !dflops || !hv || !hv_len) return fail(SPGEMM_ERR_ARG, "null output pointer");
+  *drowIds = nullptr; *dflops = nullptr;
+  if (m < 0) return fail(SPGEMM_ERR_ARG, "negative m");
+  if (!dIA) return fail(SPGEMM_ERR_ARG, "A.rowPtr is null");
+  if (!h) CHK(default_handle(&h));
+  HIPCHK(hipSetDevice(h->device));
+  CHK(ws_ensure(h, m));
+  int *ids = nullptr, *fl = nullptr, *tmpIC = nullptr;
+  auto cleanup = [&](int rc) { pool().release(ids); pool().release(fl); pool().release(tmpIC); return rc; };
+  HIPCHK(pool().alloc((void**)&ids, sizeof(int) * (size_t)std::max(m, 1)));
+  if (hipSuccess != pool().alloc((void**)&fl, sizeof(int) * ((size_t)m + 1)) ||
+      hipSuccess != pool().alloc((void**)&tmpIC, sizeof(int) * ((size_t)m + 1)))
+    return cleanup(fail(SPGEMM_ERR_HIP, "device allocation failed"));
+  int rc = launch_classify(h, dIA, dJA, dIB, m, tmpIC);
+  if (rc) return cleanup(rc);
+  hipStream_t s = h->stream;
+  if (m > 0) {
+    hipMemcpyAsync(ids, h->rowIds, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(k_gather_flops, dim3(cdiv(m, 256)), dim3(256), 0, s, m, h->rowIds, h->rowFlops, fl);
+    if ((rc = launch_scan(h, fl, m, &h->dsmall->nnzC64))) return cleanup(rc);
+  } else {
+    hipMemsetAsync(fl, 0, sizeof(int), s);
+  }
+  if (hipMemcpyAsync(h->hsmall, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return cleanup(fail(SPGEMM_ERR_HIP, "classify failed: %s", hipGetErrorString(hipGetLastError())));
+  hv_from_binptr(h->hsmall->binPtr, m, hv, hv_len);
+  if (total_flops) *total_flops = (long long)h->hsmall->totalP;
+  h->stats.total_flops = (long long)h->hsmall->totalP;
+  for (int b = 0; b < NBINS; ++b) h->stats.bin_rows[b] = h->hsmall->binPtr[b + 1] - h->hsmall->binPtr[b];
+  pool().release(tmpIC);
+  *drowIds = ids;
+  *dflops = fl;
+  return SPGEMM_OK;
+}
+
+// rebuild the internal view (rowFlops by row, 8-bin binPtr, IC presets) from a caller-held classification
+__global__ void k_unpack_classify(int m, const int* __restrict__ rowIds, const int* __restrict__ dflops,
+                                  int* __restrict__ rowFlops, int* __restrict__ IC, int lo6, int* __restrict__ n6) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  int is6 = 0;
+  if (q < m) {
+    const int r = rowIds[q];
+    // dflops is an int scan (like the reference's): differences stay exact modulo 2^32
+    const unsigned f = (unsigned)dflops[q + 1] - (unsigned)dflops[q];
+    rowFlops[r] = f > 0x7fffffffu ? 0x7fffffff : (int)f;
+    if (f <= 1u) IC[r] = (int)f;
+    is6 = (q >= lo6 && f <= 4096u) ? 1 : 0;
+  }
+  const unsigned long long mk = __ballot(is6);
+  if (smf::lane_id() == 0 && mk) atomicAdd(n6, __popcll(mk));
+}
+
+__global__ void k_binptr_from_hv(int* binPtr, int h2, int h3, int h4, int h5, int h6, int h7, int m, const int* n6) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    binPtr[0] = 0; binPtr[1] = h2 - 1; binPtr[2] = h3 - 1; binPtr[3] = h4 - 1; binPtr[4] = h5 - 1;
+    binPtr[5] = h6 - 1; binPtr[6] = h7 - 1; binPtr[7] = h7 - 1 + *n6; binPtr[8] = m;
+  }
+}
+
+static int k_unpack_launch(spgemm_handle* h, int m, const PreClass& pre, int* dIC) {
+  if (!pre.drowIds || !pre.hv || !pre.dflops) return fail(SPGEMM_ERR_ARG, "classification pointers are null");
+  const int* hv = pre.hv;
+  for (int b = 0; b < 8; ++b)
+    if (hv[b] > hv[b + 1]) return fail(SPGEMM_ERR_ARG, "hv is not monotone");
+  if (hv[8] != m + 1 || hv[1] != 0 || hv[2] < 1) return fail(SPGEMM_ERR_ARG, "hv does not describe %d rows", m);
+  HIPCHK(hipMemsetAsync(h->dsmall, 0, sizeof(HostMirror), h->stream));
+  if (m > 0) {
+    int* n6 = &h->dsmall->pad;
+    hipLaunchKernelGGL(k_unpack_classify, dim3(cdiv(m, 256)), dim3(256), 0, h->stream, m, pre.drowIds, pre.dflops,
+                       h->rowFlops, dIC, hv[7] - 1, n6);
+    hipLaunchKernelGGL(k_binptr_from_hv, dim3(1), dim3(64), 0, h->stream, h->dsmall->binPtr, hv[2], hv[3], hv[4], hv[5],
+                       hv[6], hv[7], m, n6);
+  }
+  HIPCHK(hipGetLastError());
+  return SPGEMM_OK;
+}
+
+extern "C" int hip_sgpuSpMM(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, int nnzA,
+                            const int* dIB, const int* dJB, const float* dB, int nnzB, int m, int k, int n,
+                            const int* drowIds, const int hv[SPGEMM_HV_LEN], const int* dflops, int** dIC, int** dJC,
+                            float** dC, int* nnzC) {
+  PreClass pre{drowIds, hv, dflops};
+  return spgemm_device(h, dIA, dJA, dA, nnzA, dIB, dJB, dB, nnzB, m, k, n, &pre, dIC, dJC, dC, nnzC);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host arrays in / host arrays out
+// ------------------------------------------------------------------------------------------------
+static int validate_host_csr(const int* I, const int* J, int rows, int cols, int nnz, const char* who) {
+  if (I[0] != 0) return fail(SPGEMM_ERR_INPUT, "%s: rowPtr[0]=%d, expected 0", who, I[0]);
+  for (int i = 0; i < rows; ++i)
+    if (I[i + 1] < I[i]) return fail(SPGEMM_ERR_INPUT, "%s: rowPtr decreases at row %d", who, i);
+  if (I[rows] != nnz) return fail(SPGEMM_ERR_INPUT, "%s: rowPtr[rows]=%d but nnz=%d", who, I[rows], nnz);
+  for (int p = 0; p < nnz; ++p)
+    if ((unsigned)J[p] >= (unsigned)cols) return fail(SPGEMM_ERR_INPUT, "%s: colInd[%d]=%d outside [0,%d)", who, p, J[p], cols);
+  return SPGEMM_OK;
+}
+
+extern "C" int hip_CSR_SpMM(const int* IA, const int* JA, const float* A, int nnzA, const int* IB, const int* JB,
+                            const float* B, int nnzB, int** IC, int** JC, float** C, int* nnzC, int m, int k, int n) {
+  if (!IC || !JC || !C || !nnzC) return fail(SPGEMM_ERR_ARG, "output pointer is null");
+  *IC = nullptr; *JC = nullptr; *C = nullptr; *nnzC = 0;
+  if (m < 0 || k < 0 || n < 0) return fail(SPGEMM_ERR_ARG, "negative dimension");
+  CHK(check_common(IA, JA, A, nnzA, "A"));
+  CHK(check_common(IB, JB, B, nnzB, "B"));
+  CHK(validate_host_csr(IA, JA, m, k, nnzA, "A"));
+  CHK(validate_host_csr(IB, JB, k, n, nnzB, "B"));
+  spgemm_handle* h = nullptr;
+  CHK(default_handle(&h));
+  int *dIA = nullptr, *dJA = nullptr, *dIB = nullptr, *dJB = nullptr, *dIC = nullptr, *dJC = nullptr;
+  float *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  int *hIC = nullptr, *hJC = nullptr;
+  float* hC = nullptr;
+  auto cleanup = [&](int rc) {
+    for (void* p : {(void*)dIA, (void*)dJA, (void*)dA, (void*)dIB, (void*)dJB, (void*)dB, (void*)dIC, (void*)dJC, (void*)dC})
+      pool().release(p);
+    if (rc != SPGEMM_OK) { free(hIC); free(hJC); free(hC); }
+    return rc;
+  };
+  const bool same = (IA == IB && JA == JB && A == B && nnzA == nnzB && m == k);  // C = A*A: upload once
+  int rc;
+#define UP(dst, src, bytes)                                                                        \
+  if ((rc = spgemm_hip_malloc((void**)&dst, (bytes))) || (rc = spgemm_hip_memcpy_h2d(dst, src, (bytes)))) return cleanup(rc);
+  UP(dIA, IA, sizeof(int) * ((size_t)m + 1));
+  UP(dJA, JA, sizeof(int) * (size_t)nnzA);
+  UP(dA, A, sizeof(float) * (size_t)nnzA);
+  if (!same) {
+    UP(dIB, IB, sizeof(int) * ((size_t)k + 1));
+    UP(dJB, JB, sizeof(int) * (size_t)nnzB);
+    UP(dB, B, sizeof(float) * (size_t)nnzB);
+  }
+#undef UP
+  int nz = 0;
+  rc = hip_gpuSpMM(h, dIA, dJA, dA, nnzA, same ? dIA : dIB, same ? dJA : dJB, same ? dA : dB, nnzB, m, k, n, &dIC,
+                   &dJC, &dC, &nz);
+  if (rc) return cleanup(rc);
+  // outputs must be malloc()ed: the caller's CSR::dispose() is free() (nlibs/CSR.h:323-327)
+  hIC = (int*)malloc(sizeof(int) * ((size_t)m + 1));
+  hJC = (int*)malloc(sizeof(int) * (size_t)std::max(nz, 1));
+  hC = (float*)malloc(sizeof(float) * (size_t)std::max(nz, 1));
+  if (!hIC || !hJC || !hC) return cleanup(fail(SPGEMM_ERR_NOMEM, "host malloc of C failed"));
+  if ((rc = spgemm_hip_memcpy_d2h(hIC, dIC, sizeof(int) * ((size_t)m + 1))) ||
+      (rc = spgemm_hip_memcpy_d2h(hJC, dJC, sizeof(int) * (size_t)nz)) ||
+      (rc = spgemm_hip_memcpy_d2h(hC, dC, sizeof(float) * (size_t)nz)))
+    return cleanup(rc);
+  *IC = hIC; *JC = hJC; *C = hC; *nnzC = nz;
+  return cleanup(SPGEMM_OK);
+}
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" int hip_csr_sort_rows(spgemm_handle* h, int m, const int* dIC, int* dJC, float* dC) {
+  if (m < 0 || !dIC) return fail(SPGEMM_ERR_ARG, "bad argument");
+  if (!h) CHK(default_handle(&h));
+  HIPCHK(hipSetDevice(h->device));
+  if (m > 0) {
+    hipLaunchKernelGGL(k_sort_rows, dim3(clampi(m, 1, h->numCU * 8)), dim3(256), 0, h->stream, m, dIC, dJC, dC);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_hip_selftest(spgemm_handle* h) {
+  if (!h) CHK(default_handle(&h));
+  HIPCHK(hipSetDevice(h->device));
+  const int nb = 64;
+  std::vector<int> host(nb * WAVE);
+  unsigned x = 12345u;
+  for (auto& v : host) { x = x * 1664525u + 1013904223u; v = (int)((x >> 8) & 0xfffff); }
+  int* din = nullptr;
+  int* dbad = nullptr;
+  HIPCHK(hipMalloc((void**)&din, sizeof(int) * host.size()));
+  HIPCHK(hipMalloc((void**)&dbad, sizeof(int)));
+  HIPCHK(hipMemcpy(din, host.data(), sizeof(int) * host.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(dbad, 0, sizeof(int)));
+  hipLaunchKernelGGL(k_selftest, dim3(nb), dim3(WAVE), 0, h->stream, din, dbad);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int bad = -1;
+  HIPCHK(hipMemcpy(&bad, dbad, sizeof(int), hipMemcpyDeviceToHost));
+  hipFree(din);
+  hipFree(dbad);
+  if (bad != 0) return fail(SPGEMM_ERR_INTERNAL, "wave primitive self-test: %d lanes disagree", bad);
+  return SPGEMM_OK;
+}

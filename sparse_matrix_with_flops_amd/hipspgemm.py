@@ -1,0 +1,340 @@
+"""ctypes binding of libspgemm_hip.so (include/spgemm_hip.h) + a thin Python mirror of the
+reference's host-side call surface for the SpGEMM path.
+
+Mirrors (reference file:line):
+  CSR                         struct CSR                       nlibs/CSR.h:23-50
+  CSR.hip_spmm(B)             CSR::spmm / omp_spmm / ...       nlibs/CSR.cc:59-208   (host in, host out)
+  CSR.toGpuCSR / toCpuCSR / deviceDispose                      nlibs/CSR.cc:342-379
+  gpuSpMMWrapper(dA, dB)      gpuSpMMWrapper                   nlibs/gpus/gpu_csr_kernel.cu:128-173
+  gpuFlopsClassify(dA, dB)    gpuFlopsClassify                 mindex2-cuda/flops.cu:110-185
+  sgpuSpMMWrapper(...)        sgpuSpMMWrapper                  mindex2-cuda/kernel.cu:311-427
+  scudaSpMM(hA, hB)           scudaSpMM                        mindex2-cuda/nGpuSpMM.cc:245-279
+
+There is no CPU fallback: if the library or a HIP device is missing, calls raise SpgemmError.
+PyTorch is not needed here; bench.py / dist.py use it only for device memory and torch.distributed.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspgemm_hip.so")
+
+NBINS = 8
+HV_LEN = 9
+NKERNELS = 16
+_I = C.POINTER(C.c_int)
+_F = C.POINTER(C.c_float)
+
+EXPORTS = [
+    "spgemm_hip_last_error", "spgemm_hip_device_count", "spgemm_hip_create", "spgemm_hip_destroy",
+    "spgemm_hip_get_stats", "spgemm_hip_stream", "spgemm_hip_malloc", "spgemm_hip_free",
+    "spgemm_hip_memcpy_h2d", "spgemm_hip_memcpy_d2h", "hip_CSR_SpMM", "hip_gpuSpMM",
+    "hip_gpuFlopsClassify", "hip_sgpuSpMM", "hip_csr_sort_rows", "spgemm_hip_selftest",
+    "hip_spgemm_symbolic", "hip_spgemm_numeric", "hip_csr_row_flops", "spgemm_hip_kernel_name",
+]
+
+
+class SpgemmError(RuntimeError):
+    pass
+
+
+class Stats(C.Structure):
+    _fields_ = [("total_flops", C.c_longlong), ("nnzC", C.c_int), ("bin_rows", C.c_int * NBINS),
+                ("ms_classify", C.c_float), ("ms_symbolic", C.c_float), ("ms_scan_alloc", C.c_float),
+                ("ms_numeric", C.c_float), ("ms_total", C.c_float), ("ms_kernel", C.c_float * NKERNELS)]
+
+    def as_dict(self):
+        return {"total_flops": int(self.total_flops), "nnzC": int(self.nnzC), "bin_rows": [int(x) for x in self.bin_rows],
+                "ms_classify": float(self.ms_classify), "ms_symbolic": float(self.ms_symbolic),
+                "ms_scan_alloc": float(self.ms_scan_alloc), "ms_numeric": float(self.ms_numeric),
+                "ms_total": float(self.ms_total),
+                "ms_kernel": {kernel_name(i): float(self.ms_kernel[i]) for i in range(NKERNELS)
+                              if kernel_name(i) and self.ms_kernel[i] > 0.0}}
+
+
+_lib = None
+
+
+def lib():
+    """Load libspgemm_hip.so (built in tree by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SpgemmError(f"{LIB_PATH} is missing: run `make -C sparse_matrix_with_flops_amd/csrc` "
+                              "(there is no CPU fallback for the HIP path)")
+        L = C.CDLL(LIB_PATH)
+        L.spgemm_hip_last_error.restype = C.c_char_p
+        L.spgemm_hip_stream.restype = C.c_void_p
+        L.spgemm_hip_stream.argtypes = [C.c_void_p]
+        L.spgemm_hip_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.spgemm_hip_destroy.argtypes = [C.c_void_p]
+        L.spgemm_hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.spgemm_hip_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        L.spgemm_hip_free.argtypes = [C.c_void_p]
+        L.spgemm_hip_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.spgemm_hip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.hip_CSR_SpMM.argtypes = [_I, _I, _F, C.c_int, _I, _I, _F, C.c_int, C.POINTER(_I), C.POINTER(_I),
+                                   C.POINTER(_F), _I, C.c_int, C.c_int, C.c_int]
+        dev_in = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.hip_gpuSpMM.argtypes = [C.c_void_p] + dev_in + dev_in + [C.c_int, C.c_int, C.c_int] + \
+            [C.POINTER(C.c_void_p)] * 3 + [_I]
+        L.hip_gpuFlopsClassify.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _I,
+                                           C.POINTER(C.c_longlong)]
+        L.hip_sgpuSpMM.argtypes = [C.c_void_p] + dev_in + dev_in + [C.c_int, C.c_int, C.c_int] + \
+            [C.c_void_p, _I, C.c_void_p] + [C.POINTER(C.c_void_p)] * 3 + [_I]
+        L.hip_spgemm_symbolic.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_void_p, _I]
+        L.hip_spgemm_numeric.argtypes = [C.c_void_p] + dev_in + dev_in + [C.c_int, C.c_int, C.c_int,
+                                                                            C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hip_csr_row_flops.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.POINTER(C.c_longlong)]
+        L.spgemm_hip_kernel_name.restype = C.c_char_p
+        L.spgemm_hip_kernel_name.argtypes = [C.c_int]
+        L.hip_csr_sort_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.spgemm_hip_selftest.argtypes = [C.c_void_p]
+        L.free = C.CDLL(None).free
+        L.free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def kernel_name(i):
+    return lib().spgemm_hip_kernel_name(int(i)).decode()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise SpgemmError(f"{what} failed with status {rc}: {lib().spgemm_hip_last_error().decode(errors='replace')}")
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().spgemm_hip_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class Handle:
+    """spgemm_handle: one HIP stream + workspace on one device."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().spgemm_hip_create(C.byref(self._h), int(device)), "spgemm_hip_create")
+        self.device = device
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def stats(self):
+        s = Stats()
+        _check(lib().spgemm_hip_get_stats(self._h, C.byref(s)), "spgemm_hip_get_stats")
+        return s.as_dict()
+
+    def stream(self):
+        return lib().spgemm_hip_stream(self._h)
+
+    def selftest(self):
+        _check(lib().spgemm_hip_selftest(self._h), "spgemm_hip_selftest")
+
+    def close(self):
+        if self._h:
+            lib().spgemm_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------
+# device buffers
+# ---------------------------------------------------------------------------------------------
+def dev_alloc(nbytes):
+    p = C.c_void_p()
+    _check(lib().spgemm_hip_malloc(C.byref(p), max(int(nbytes), 1)), "spgemm_hip_malloc")
+    return p.value
+
+
+def dev_free(ptr):
+    if ptr:
+        _check(lib().spgemm_hip_free(C.c_void_p(ptr)), "spgemm_hip_free")
+
+
+def h2d(arr):
+    arr = np.ascontiguousarray(arr)
+    p = dev_alloc(arr.nbytes)
+    if arr.nbytes:
+        _check(lib().spgemm_hip_memcpy_h2d(C.c_void_p(p), arr.ctypes.data_as(C.c_void_p), arr.nbytes), "h2d")
+    return p
+
+
+def d2h(ptr, n, dtype):
+    out = np.empty(int(n), dtype=dtype)
+    if out.nbytes:
+        _check(lib().spgemm_hip_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes), "d2h")
+    return out
+
+
+class CSR:
+    """Mirror of the reference's `struct CSR` (nlibs/CSR.h:23-50): three arrays + rows/cols/nnz.
+    Host CSRs hold numpy arrays; device CSRs (from toGpuCSR / gpuSpMMWrapper) hold raw device
+    pointers in the same fields, exactly as the reference reuses one struct for both."""
+
+    def __init__(self, values=None, colInd=None, rowPtr=None, rows=0, cols=0, nnz=0, on_device=False):
+        self.values, self.colInd, self.rowPtr = values, colInd, rowPtr
+        self.rows, self.cols, self.nnz = int(rows), int(cols), int(nnz)
+        self.on_device = on_device
+
+    @staticmethod
+    def from_arrays(rowPtr, colInd, values, rows, cols):
+        rowPtr = np.ascontiguousarray(rowPtr, dtype=np.int32)
+        return CSR(np.ascontiguousarray(values, dtype=np.float32), np.ascontiguousarray(colInd, dtype=np.int32),
+                   rowPtr, rows, cols, int(rowPtr[-1]) if len(rowPtr) else 0)
+
+    # -- nlibs/CSR.cc:342-379 ------------------------------------------------------------------
+    def toGpuCSR(self):
+        assert not self.on_device
+        return CSR(h2d(self.values), h2d(self.colInd), h2d(self.rowPtr), self.rows, self.cols, self.nnz, True)
+
+    def toCpuCSR(self):
+        assert self.on_device
+        return CSR(d2h(self.values, self.nnz, np.float32), d2h(self.colInd, self.nnz, np.int32),
+                   d2h(self.rowPtr, self.rows + 1, np.int32), self.rows, self.cols, self.nnz, False)
+
+    def deviceDispose(self):
+        assert self.on_device
+        for p in (self.values, self.colInd, self.rowPtr):
+            dev_free(p)
+        self.values = self.colInd = self.rowPtr = None
+
+    # -- nlibs/CSR.cc:73-86 -------------------------------------------------------------------
+    def makeOrdered(self):
+        assert not self.on_device
+        row_of = np.repeat(np.arange(self.rows, dtype=np.int64), np.diff(self.rowPtr.astype(np.int64)))
+        order = np.lexsort((self.colInd, row_of))
+        self.colInd = np.ascontiguousarray(self.colInd[order])
+        self.values = np.ascontiguousarray(self.values[order])
+
+    # -- the drop-in: same role as CSR::spmm/omp_spmm/... (nlibs/CSR.cc:59-208) ----------------
+    def hip_spmm(self, B):
+        """C = self * B through hip_CSR_SpMM (host arrays in, malloc'd host arrays out)."""
+        assert not self.on_device and not B.on_device
+        if self.cols != B.rows:
+            raise SpgemmError(f"shape mismatch: A is {self.rows}x{self.cols}, B is {B.rows}x{B.cols}")
+        L = lib()
+        ic, jc, cv, nnz = _I(), _I(), _F(), C.c_int(0)
+        rc = L.hip_CSR_SpMM(self.rowPtr.ctypes.data_as(_I), self.colInd.ctypes.data_as(_I), self.values.ctypes.data_as(_F),
+                            self.nnz, B.rowPtr.ctypes.data_as(_I), B.colInd.ctypes.data_as(_I), B.values.ctypes.data_as(_F),
+                            B.nnz, C.byref(ic), C.byref(jc), C.byref(cv), C.byref(nnz), self.rows, self.cols, B.cols)
+        _check(rc, "hip_CSR_SpMM")
+        n = nnz.value
+        rp = np.ctypeslib.as_array(ic, shape=(self.rows + 1,)).copy()
+        ci = np.ctypeslib.as_array(jc, shape=(n,)).copy() if n else np.zeros(0, np.int32)
+        v = np.ctypeslib.as_array(cv, shape=(n,)).copy() if n else np.zeros(0, np.float32)
+        for p in (ic, jc, cv):                      # CSR::dispose() == free() (nlibs/CSR.h:323-327)
+            L.free(C.cast(p, C.c_void_p))
+        return CSR(v, ci, rp, self.rows, B.cols, n)
+
+
+def _dev_args(M):
+    return [C.c_void_p(M.rowPtr), C.c_void_p(M.colInd), C.c_void_p(M.values), M.nnz]
+
+
+def gpuSpMMWrapper(dA, dB, handle=None):
+    """CSR gpuSpMMWrapper(const CSR& dA, const CSR& dB) — device CSRs in, device CSR out."""
+    assert dA.on_device and dB.on_device
+    if dA.cols != dB.rows:
+        raise SpgemmError("shape mismatch")
+    ic, jc, cv, nnz = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+    rc = lib().hip_gpuSpMM(handle.ptr if handle else None, *_dev_args(dA), *_dev_args(dB), dA.rows, dA.cols, dB.cols,
+                           C.byref(ic), C.byref(jc), C.byref(cv), C.byref(nnz))
+    _check(rc, "hip_gpuSpMM")
+    return CSR(cv.value, jc.value, ic.value, dA.rows, dB.cols, nnz.value, True)
+
+
+def gpu_spmm_raw(handle, IA, JA, VA, nnzA, IB, JB, VB, nnzB, m, k, n):
+    """Raw-pointer form for callers that own device memory elsewhere (e.g. torch tensors' data_ptr())."""
+    ic, jc, cv, nnz = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+    rc = lib().hip_gpuSpMM(handle.ptr if handle else None, C.c_void_p(IA), C.c_void_p(JA), C.c_void_p(VA), int(nnzA),
+                           C.c_void_p(IB), C.c_void_p(JB), C.c_void_p(VB), int(nnzB), int(m), int(k), int(n),
+                           C.byref(ic), C.byref(jc), C.byref(cv), C.byref(nnz))
+    _check(rc, "hip_gpuSpMM")
+    return ic.value, jc.value, cv.value, nnz.value
+
+
+def spgemm_symbolic_raw(handle, IA, JA, nnzA, IB, JB, nnzB, m, k, n, IC_out):
+    """Phase 1 on raw device pointers: fills IC_out[m+1] (C.rowPtr), returns nnzC."""
+    nnz = C.c_int(0)
+    _check(lib().hip_spgemm_symbolic(handle.ptr, C.c_void_p(IA), C.c_void_p(JA), int(nnzA), C.c_void_p(IB),
+                                     C.c_void_p(JB), int(nnzB), int(m), int(k), int(n), C.c_void_p(IC_out),
+                                     C.byref(nnz)), "hip_spgemm_symbolic")
+    return nnz.value
+
+
+def spgemm_numeric_raw(handle, IA, JA, VA, nnzA, IB, JB, VB, nnzB, m, k, n, IC, JC_out, C_out):
+    """Phase 2 on raw device pointers: writes JC_out/C_out (caller-owned, nnzC entries each)."""
+    _check(lib().hip_spgemm_numeric(handle.ptr, C.c_void_p(IA), C.c_void_p(JA), C.c_void_p(VA), int(nnzA),
+                                    C.c_void_p(IB), C.c_void_p(JB), C.c_void_p(VB), int(nnzB), int(m), int(k), int(n),
+                                    C.c_void_p(IC), C.c_void_p(JC_out), C.c_void_p(C_out)), "hip_spgemm_numeric")
+
+
+def row_flops_raw(handle, IA, JA, IB, m, out_ptr):
+    """Per-row product counts into a device int[m]; returns P."""
+    tot = C.c_longlong(0)
+    _check(lib().hip_csr_row_flops(handle.ptr if handle else None, C.c_void_p(IA), C.c_void_p(JA), C.c_void_p(IB),
+                                   int(m), C.c_void_p(out_ptr), C.byref(tot)), "hip_csr_row_flops")
+    return tot.value
+
+
+def gpuFlopsClassify(dA, dB, handle=None):
+    """-> (hv list, drowIds devptr, dflops devptr, total_flops).  hv has the reference's length (max bin + 2)."""
+    assert dA.on_device and dB.on_device
+    ids, fl = C.c_void_p(), C.c_void_p()
+    hv = (C.c_int * HV_LEN)()
+    hv_len, tot = C.c_int(0), C.c_longlong(0)
+    rc = lib().hip_gpuFlopsClassify(handle.ptr if handle else None, C.c_void_p(dA.rowPtr), C.c_void_p(dA.colInd),
+                                    C.c_void_p(dB.rowPtr), dA.rows, dA.cols, C.byref(ids), C.byref(fl), hv,
+                                    C.byref(hv_len), C.byref(tot))
+    _check(rc, "hip_gpuFlopsClassify")
+    return [int(x) for x in hv], hv_len.value, ids.value, fl.value, tot.value
+
+
+def sgpuSpMMWrapper(dA, dB, drowIds, hv, dflops, handle=None):
+    assert dA.on_device and dB.on_device
+    hv_arr = (C.c_int * HV_LEN)(*hv)
+    ic, jc, cv, nnz = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+    rc = lib().hip_sgpuSpMM(handle.ptr if handle else None, *_dev_args(dA), *_dev_args(dB), dA.rows, dA.cols, dB.cols,
+                            C.c_void_p(drowIds), hv_arr, C.c_void_p(dflops), C.byref(ic), C.byref(jc), C.byref(cv),
+                            C.byref(nnz))
+    _check(rc, "hip_sgpuSpMM")
+    return CSR(cv.value, jc.value, ic.value, dA.rows, dB.cols, nnz.value, True)
+
+
+def scudaSpMM(hA, hB, handle=None):
+    """Host CSRs in, host CSR out via classify + binned SpGEMM (mindex2-cuda/nGpuSpMM.cc:245-279)."""
+    dA = hA.toGpuCSR()
+    dB = dA if hB is hA else hB.toGpuCSR()
+    try:
+        hv, hv_len, ids, fl, _ = gpuFlopsClassify(dA, dB, handle)
+        try:
+            dC = sgpuSpMMWrapper(dA, dB, ids, hv, fl, handle)
+        finally:
+            dev_free(ids)
+            dev_free(fl)
+        hC = dC.toCpuCSR()
+        dC.deviceDispose()
+        return hC
+    finally:
+        dA.deviceDispose()
+        if dB is not dA:
+            dB.deviceDispose()
+
+
+def sort_rows_device(dC, handle=None):
+    _check(lib().hip_csr_sort_rows(handle.ptr if handle else None, dC.rows, C.c_void_p(dC.rowPtr),
+                                   C.c_void_p(dC.colInd), C.c_void_p(dC.values)), "hip_csr_sort_rows")

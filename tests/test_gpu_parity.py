@@ -1,0 +1,254 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle, the committed golden
+vectors made from the real reference, and size-independent properties at the headline size.
+
+Parity rule (BASELINE.json north_star): rowPtr bit-exact, per-row-sorted colInd bit-exact, values within
+1e-6 relative (helpers.assert_parity).  The protocol is the reference's own GPU test
+(tests/testGpuSpMM.cc:9-46): device SpGEMM -> toCpuCSR -> makeOrdered -> compare with A.spmm(B).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import DATA, GOLDEN, assert_parity, canonical_arrays, po, random_csr, summarize, synth_csr
+from sparse_matrix_with_flops_amd import hipspgemm as hs
+
+pytestmark = pytest.mark.gpu
+
+FX = np.load(os.path.join(GOLDEN, "fixtures.npz"))
+SM = np.load(os.path.join(GOLDEN, "synth_small.npz"))
+META = json.load(open(os.path.join(GOLDEN, "golden.json")))
+
+
+def unpack(z, prefix):
+    r, c = z[prefix + "_shape"]
+    return po.CSRHost(z[prefix + "_rowPtr"], z[prefix + "_colInd"], z[prefix + "_values"], int(r), int(c))
+
+
+def to_hs(M):
+    return hs.CSR.from_arrays(M.rowPtr, M.colInd, M.values, M.rows, M.cols)
+
+
+@pytest.fixture(scope="module")
+def handle():
+    import __graft_entry__ as ge
+    ge.build()
+    assert hs.device_count() >= 1, "GPU tests need a HIP device (no CPU fallback exists)"
+    h = hs.Handle(0)
+    yield h
+    h.close()
+
+
+def hip_mul(A, B):
+    """host in / host out through hip_CSR_SpMM"""
+    hA = to_hs(A)
+    return hA.hip_spmm(hA if B is A else to_hs(B))
+
+
+def test_wave_primitives_selftest(handle):
+    handle.selftest()
+
+
+SQUARE = [n for n in sorted(os.listdir(DATA)) if "nnzC" in META["fixtures"].get(n, {})]
+
+
+@pytest.mark.parametrize("name", SQUARE)
+def test_reference_fixtures_AA(name):
+    key = name.replace(".", "_")
+    A = unpack(FX, key + "_load")
+    assert_parity(hip_mul(A, A), unpack(FX, key + "_AA"), what=name, inputs=(A, A))
+
+
+@pytest.mark.parametrize("key", ["synth_64_3_2", "synth_512_7_2", "synth_1024_9_4"])
+def test_golden_synth_small(key):
+    _, m, seed, base = key.split("_")
+    A = synth_csr(int(m), int(seed), int(base))
+    assert_parity(hip_mul(A, A), unpack(SM, key + "_AA"), what=key)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_golden_rectangular_unsorted(idx):
+    A, B, want = unpack(SM, f"rect{idx}_A"), unpack(SM, f"rect{idx}_B"), unpack(SM, f"rect{idx}_C")
+    assert_parity(hip_mul(A, B), want, what=f"rect{idx}", inputs=(A, B))
+
+
+@pytest.mark.parametrize("key", ["4096_11_2", "32768_13_2", "65536_17_4"])
+def test_synth_vs_oracle_and_golden_summary(key):
+    g = META["synth"][key]
+    A = synth_csr(g["m"], g["seed"], g["base"])
+    got = hip_mul(A, A)
+    assert_parity(got, po.omp_spmm(A, A), what=key)
+    s = summarize(got)
+    assert s["nnz"] == g["nnz"] and s["hash"] == g["hash"]
+    assert abs(s["sum"] - g["sum"]) <= 1e-6 * abs(g["sum"]) and abs(s["wsum"] - g["wsum"]) <= 1e-6 * abs(g["wsum"])
+
+
+def test_headline_config_device_resident(handle):
+    """BASELINE.json configs[1]: synthetic 262144^2, ~16 nnz/row, seed 42 — full parity vs the oracle, the
+    golden summary from the real reference, device-resident API + device row sort."""
+    g = META["synth"]["262144_42_2"]
+    A = synth_csr(262144, 42, 2)
+    dA = to_hs(A).toGpuCSR()
+    dC = hs.gpuSpMMWrapper(dA, dA, handle)
+    st = handle.stats()
+    assert st["total_flops"] == g["P"] and st["nnzC"] == g["nnz"] and sum(st["bin_rows"]) == 262144
+    raw = dC.toCpuCSR()
+    hs.sort_rows_device(dC, handle)
+    srt = dC.toCpuCSR()
+    dC.deviceDispose()
+    dA.deviceDispose()
+    want = po.omp_spmm(A, A)
+    assert_parity(raw, want, what="headline raw")
+    # device-side makeOrdered: columns ascending inside every row, same multiset
+    cs, vs = canonical_arrays(raw.rowPtr, raw.colInd, raw.values)
+    assert np.array_equal(srt.colInd, cs) and np.array_equal(srt.values, vs)
+    s = summarize(raw)
+    assert s["hash"] == g["hash"] and abs(s["sum"] - g["sum"]) <= 1e-6 * abs(g["sum"])
+
+
+def test_classify_matches_oracle(handle):
+    A = synth_csr(20000, 23, 2)
+    dA = to_hs(A).toGpuCSR()
+    hv, hv_len, ids, fl, tot = hs.gpuFlopsClassify(dA, dA, handle)
+    rowIds = hs.d2h(ids, A.rows, np.int32)
+    dflops = hs.d2h(fl, A.rows + 1, np.int32)
+    flops = po.row_flops(A, A)
+    o_ids, o_scan, o_hv, o_len = po.gpu_classify(flops)
+    assert tot == int(flops.sum())
+    assert hv == [int(x) for x in o_hv] and hv_len == o_len
+    assert sorted(rowIds.tolist()) == list(range(A.rows))
+    # same rows in every reference bin (rows of bin b sit at drowIds + hv[b] - 1, gnnz.cuh:27); ascending inside
+    for b in range(1, 8):
+        lo, hi = max(hv[b] - 1, 0), hv[b + 1] - 1
+        mine, theirs = rowIds[lo:hi], o_ids[lo:hi]
+        assert np.array_equal(np.sort(mine), np.sort(theirs)), b
+    # dflops = scan of the flops in drowIds order
+    assert dflops[0] == 0 and np.array_equal(np.diff(dflops.astype(np.int64)), flops[rowIds])
+    # binned SpGEMM on that classification == one-shot path == oracle
+    dC = hs.sgpuSpMMWrapper(dA, dA, ids, hv, fl, handle)
+    got = dC.toCpuCSR()
+    dC.deviceDispose()
+    hs.dev_free(ids)
+    hs.dev_free(fl)
+    dA.deviceDispose()
+    assert_parity(got, po.omp_spmm(A, A), what="sgpuSpMMWrapper")
+
+
+def test_scuda_spmm_host_roundtrip(handle):
+    A = synth_csr(3000, 31, 4)
+    hA = to_hs(A)
+    assert_parity(hs.scudaSpMM(hA, hA, handle), po.sequential_spmm(A, A), what="scudaSpMM")
+
+
+# ---- edge cases the reference's tests / loaders exercise ---------------------------------------
+def test_empty_and_degenerate_inputs():
+    Z = po.CSRHost(np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32), 0, 0)
+    got = hip_mul(Z, Z)
+    assert got.rows == 0 and got.nnz == 0 and list(got.rowPtr) == [0]
+    E = random_csr(50, 50, 0.0, 1)                       # no entries at all
+    got = hip_mul(E, E)
+    assert got.nnz == 0 and not got.rowPtr.any()
+    S = random_csr(200, 200, 0.01, 2)                    # most rows empty; products hit empty B rows
+    assert_parity(hip_mul(S, S), po.sequential_spmm(S, S), what="sparse-empty-rows", inputs=(S, S))
+    one = po.CSRHost([0, 1], [0], [3.0], 1, 1)
+    got = hip_mul(one, one)
+    assert list(got.rowPtr) == [0, 1] and got.values[0] == 9.0
+
+
+def test_rows_with_entries_but_zero_products():
+    # A's columns point only at empty rows of B: flops 0 with nnz(A) > 0
+    A = po.CSRHost([0, 2, 3], [1, 2, 1], [1.0, 2.0, 3.0], 2, 3)
+    B = po.CSRHost([0, 1, 1, 1], [0], [5.0], 3, 4)
+    got = hip_mul(A, B)
+    assert got.nnz == 0 and list(got.rowPtr) == [0, 0, 0]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_rectangular_unsorted(seed):
+    rng = np.random.default_rng(100 + seed)
+    r, k, c = (int(x) for x in rng.integers(1, 400, size=3))
+    A = random_csr(r, k, float(rng.uniform(0.0, 0.2)), seed, sorted_rows=False)
+    B = random_csr(k, c, float(rng.uniform(0.0, 0.2)), seed + 50, sorted_rows=False)
+    assert_parity(hip_mul(A, B), po.sequential_spmm(A, B), what=f"rand{seed}", inputs=(A, B))
+
+
+def _rows_csr(rows_cols, ncols, seed, signed=False):
+    rng = np.random.default_rng(seed)
+    rp = np.zeros(len(rows_cols) + 1, np.int32)
+    np.cumsum([len(c) for c in rows_cols], out=rp[1:])
+    ci = np.concatenate([np.asarray(c, np.int32) for c in rows_cols]) if len(rows_cols) else np.zeros(0, np.int32)
+    v = (rng.random(len(ci)) + 0.5).astype(np.float32)
+    if signed:
+        v *= rng.choice(np.array([-1.0, 1.0], np.float32), size=len(ci))
+    return po.CSRHost(rp, ci, v, len(rows_cols), ncols)
+
+
+def test_big_rows_multi_window_and_rank_passes():
+    """Rows > 4096 products; B wider than one 262144-column LDS window; > 18432 distinct columns in a row."""
+    rng = np.random.default_rng(7)
+    k, n = 3000, 700000
+    B = _rows_csr([np.sort(rng.choice(n, size=int(rng.integers(40, 120)), replace=False)) for _ in range(k)], n, 1)
+    A = _rows_csr([rng.choice(k, size=s, replace=False) for s in (400, 90, 1, 0, 700, 64, 65, 2500)], k, 2)
+    want = po.sequential_spmm(A, B)
+    assert np.diff(want.rowPtr).max() > 18432
+    assert_parity(hip_mul(A, B), want, what="big-rows")
+
+
+def test_long_A_rows_and_empty_B_rows_in_staging():
+    """A rows longer than one staging chunk (1024 / 512 / 64 entries) whose B rows are short or empty."""
+    rng = np.random.default_rng(11)
+    k, n = 6000, 5000
+    lens = rng.integers(0, 4, size=k)                     # many empty B rows
+    lens[rng.integers(0, k, size=50)] = 300
+    B = _rows_csr([np.sort(rng.choice(n, size=int(l), replace=False)) for l in lens], n, 3, signed=True)
+    A = _rows_csr([rng.choice(k, size=s, replace=False) for s in (3000, 1500, 700, 130, 66, 20, 5800)], k, 4, signed=True)
+    assert_parity(hip_mul(A, B), po.sequential_spmm(A, B), what="long-A-rows", inputs=(A, B))
+
+
+def test_every_bin_boundary():
+    """Rows engineered to sit exactly on the flop-bin edges 0,1,2,4,5,16,17,64,65,512,513,4096,4097."""
+    edges = [0, 1, 2, 4, 5, 16, 17, 64, 65, 512, 513, 4096, 4097]
+    n = 9000
+    # B row j has exactly j entries (j = 0..4097 needs k > 4097): use a dictionary of needed lengths
+    lens = sorted(set(edges))
+    B = _rows_csr([np.arange(l, dtype=np.int32) * 2 % n if l else [] for l in lens], n, 5)
+    A = _rows_csr([[lens.index(e)] for e in edges] + [[lens.index(2), lens.index(2)][:1]], len(lens), 6)
+    got = hip_mul(A, B)
+    want = po.sequential_spmm(A, B)
+    assert list(np.diff(want.rowPtr))[:len(edges)] == edges
+    assert_parity(got, want, what="bin-edges")
+
+
+# ---- properties that hold at any size -----------------------------------------------------------
+def test_identity_and_scaling_properties_full_size():
+    A = synth_csr(262144, 42, 2)
+    m = A.rows
+    Id = po.CSRHost(np.arange(m + 1, dtype=np.int32), np.arange(m, dtype=np.int32), np.ones(m, np.float32), m, m)
+    got = hip_mul(A, Id)                                   # A*I == A exactly
+    assert np.array_equal(got.rowPtr, A.rowPtr)
+    gc, gv = canonical_arrays(got.rowPtr, got.colInd, got.values)
+    assert np.array_equal(gc, A.colInd) and np.array_equal(gv, A.values)
+    got = hip_mul(Id, A)                                   # I*A == A exactly
+    gc, gv = canonical_arrays(got.rowPtr, got.colInd, got.values)
+    assert np.array_equal(got.rowPtr, A.rowPtr) and np.array_equal(gc, A.colInd) and np.array_equal(gv, A.values)
+
+
+def test_scaling_linearity_medium():
+    A = synth_csr(16384, 77, 2)
+    A2 = po.CSRHost(A.rowPtr, A.colInd, A.values * np.float32(2.0), A.rows, A.cols)
+    c1, c2 = hip_mul(A, A), hip_mul(A2, A)
+    assert np.array_equal(c1.rowPtr, c2.rowPtr)
+    k1, v1 = canonical_arrays(c1.rowPtr, c1.colInd, c1.values)
+    k2, v2 = canonical_arrays(c2.rowPtr, c2.colInd, c2.values)
+    assert np.array_equal(k1, k2)
+    assert np.allclose(v2, 2.0 * v1, rtol=2e-6, atol=0)
+
+
+def test_error_behaviour():
+    A = to_hs(random_csr(5, 7, 0.5, 1))
+    with pytest.raises(hs.SpgemmError):
+        A.hip_spmm(A)                                      # 5x7 times 5x7: the reference asserts (CSR.cc:60)
+    bad = hs.CSR.from_arrays([0, 2, 4], [0, 9, 1, 0], [1, 1, 1, 1], 2, 2)   # column 9 out of range
+    with pytest.raises(hs.SpgemmError):
+        bad.hip_spmm(bad)
