@@ -36,16 +36,17 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MI
 
 
 def bin_of(f):
-    edges = np.array([0, 1, 4, 16, 64, 512, 4096], dtype=np.int64)   # bin b holds flops <= edges[b]; last bin beyond
+    edges = np.array([0, 1, 4, 16, 64, 512, 2048, 4096], dtype=np.int64)   # bin b holds flops <= edges[b]; last bin beyond
     return np.searchsorted(edges, f, side="left").astype(np.int64)
 
 
 # which bins each kernel covers, and whether it is a symbolic (keys only) or numeric launch
 KERNEL_BINS = {
-    "k_sym_small<4,32>": ((2, 3), "sym"), "k_sym_small<8,128>": ((4,), "sym"), "k_sym_hash<1,1024>": ((5,), "sym"),
-    "k_sym_hash<8,8192>": ((6,), "sym"), "k_sym_big": ((7,), "sym"),
-    "k_num_small<4,32>": ((1, 2, 3), "num"), "k_num_small<8,128>": ((4,), "num"), "k_num_hash<1,1024>": ((5,), "num"),
-    "k_num_hash<8,8192>": ((6,), "num"), "k_num_big": ((7,), "num"),
+    "k_sym_small<4,32>": ((2, 3), "sym"), "k_sym_g16": ((4,), "sym"), "k_sym_hash<1,1024>": ((5,), "sym"),
+    "k_sym_hash<4,4096>": ((6,), "sym"), "k_sym_hash<8,8192>": ((7,), "sym"), "k_sym_big": ((8,), "sym"),
+    "k_num_small<4,32>": ((1, 2, 3), "num"), "k_num_g16": ((4,), "num"), "k_num_hash<1,1024>": ((5,), "num"),
+    "k_num_hash<4,4096>": ((6,), "num"), "k_num_hash<8,8192>": ((7,), "num"), "k_num_big": ((8,), "num"),
+    "k_num_bighash": ((8,), "num"),
 }
 
 
@@ -152,7 +153,7 @@ def main():
                     rowPtrC.cpu().numpy().astype(np.int64)[job.r0:job.r1]) if world > 1 else np.diff(rowPtrC.cpu().numpy().astype(np.int64))
         b = bin_of(flops_rows)
         per_bin = {}
-        for q in range(8):
+        for q in range(9):
             sel = b == q
             per_bin[q] = (int(sel.sum()), int(np.diff(rpl)[sel].sum()), int(flops_rows[sel].sum()), int(cnt_rows[sel].sum()))
         avg = {k_: v_ / args.steps for k_, v_ in kern_ms.items()}

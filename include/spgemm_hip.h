@@ -31,10 +31,10 @@ extern "C" {
 #define SPGEMM_ERR_NODEVICE      7   /* no HIP device: the product path has NO CPU fallback           */
 
 /* internal row bins by intermediate-product count ("flops") */
-#define SPGEMM_NBINS             8
+#define SPGEMM_NBINS             9
 /* reference-visible bin boundaries: hv[] as returned by gpuFlopsClassify (mindex2-cuda/flops.cu:96-107) */
 #define SPGEMM_HV_LEN            9
-#define SPGEMM_NKERNELS          16
+#define SPGEMM_NKERNELS          20
 
 typedef struct spgemm_handle spgemm_handle;
 
@@ -42,7 +42,7 @@ typedef struct spgemm_handle spgemm_handle;
 typedef struct spgemm_stats {
   long long total_flops;          /* P = sum over A nonzeros of nnz(B row): "intermediate_nnz"           */
   int       nnzC;
-  int       bin_rows[SPGEMM_NBINS];/* rows per internal bin {0 | 1 | 2-4 | 5-16 | 17-64 | 65-512 | 513-4096 | >4096} */
+  int       bin_rows[SPGEMM_NBINS];/* rows per internal bin {0 | 1 | 2-4 | 5-16 | 17-64 | 65-512 | 513-2048 | 2049-4096 | >4096} */
   float     ms_classify;          /* HIP-event times on the handle's stream                              */
   float     ms_symbolic;
   float     ms_scan_alloc;
@@ -55,9 +55,10 @@ typedef struct spgemm_stats {
 /* kernel ids for spgemm_stats.ms_kernel / spgemm_hip_kernel_name */
 enum {
   SPGEMM_K_ROW_FLOPS = 0, SPGEMM_K_BIN_SCAN, SPGEMM_K_SCATTER,
-  SPGEMM_K_SYM_SMALL4, SPGEMM_K_SYM_SMALL8, SPGEMM_K_SYM_HASH1, SPGEMM_K_SYM_HASH8, SPGEMM_K_SYM_BIG,
+  SPGEMM_K_SYM_SMALL4, SPGEMM_K_SYM_G16, SPGEMM_K_SYM_HASH1, SPGEMM_K_SYM_HASH4, SPGEMM_K_SYM_HASH8, SPGEMM_K_SYM_BIG,
   SPGEMM_K_SCAN,
-  SPGEMM_K_NUM_SMALL4, SPGEMM_K_NUM_SMALL8, SPGEMM_K_NUM_HASH1, SPGEMM_K_NUM_HASH8, SPGEMM_K_NUM_BIG
+  SPGEMM_K_NUM_SMALL4, SPGEMM_K_NUM_G16, SPGEMM_K_NUM_HASH1, SPGEMM_K_NUM_HASH4, SPGEMM_K_NUM_HASH8, SPGEMM_K_NUM_BIG,
+  SPGEMM_K_NUM_BIGHASH
 };
 const char* spgemm_hip_kernel_name(int id);
 

@@ -11,13 +11,15 @@
 //                          gpu_CSR_IC_nnzC                   nlibs/gpus/gpu_csr_kernel.cu:44-82
 //   k_num_small/k_num_hash sgpu_SpGEMM_mid / fp1 / fp2 / fpl4 mindex2-cuda/gspgemm.cuh:2-293
 //                          hashCASAdd2                       mindex2-cuda/casHash.cuh:34-43
-//   k_num_big              sgpu_SpGEMM_olarge (dense map)    "mindex2-cuda/\":143-213
+//   k_num_big*             sgpu_SpGEMM_olarge (dense map)    "mindex2-cuda/\":143-213
 //
 // CDNA4 choices: 64-lane ballots / DPP scans instead of __syncthreads()-stepped sub-warp scans;
 // products of one C row are flattened over all lanes (B rows of a power-law graph are short: a
-// "lanes stride one B row" mapping leaves >90% of a wave idle); LDS tables sized per row; rows with
-// more than 4096 products use an LDS column bitmap + popcount ranks (160 KB LDS per CU) instead
-// of a global-memory dense map.  No MFMA: this is index/scatter work.
+// "lanes stride one B row" mapping leaves >90% of a wave idle); several rounds of products are kept
+// in flight per wave (the path is latency-bound, not issue-bound); LDS tables sized per row; rows with
+// more than 4096 products use either an LDS column bitmap + popcount ranks (n <= 262144: sorted output,
+// no probing) or a multi-pass 128 KB LDS hash (any n) — 160 KB LDS per CU is what makes both possible.
+// No MFMA: this is index/scatter work.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,7 +27,7 @@
 namespace smf {
 
 constexpr int WAVE = 64;
-constexpr int NBINS = 8;  // {0 | 1 | 2-4 | 5-16 | 17-64 | 65-512 | 513-4096 | >4096}
+constexpr int NBINS = 9;  // {0 | 1 | 2-4 | 5-16 | 17-64 | 65-512 | 513-2048 | 2049-4096 | >4096}
 constexpr int EMPTY_KEY = -1;
 
 __host__ __device__ __forceinline__ int bin_of(unsigned long long f) {
@@ -35,8 +37,9 @@ __host__ __device__ __forceinline__ int bin_of(unsigned long long f) {
   if (f <= 16) return 3;
   if (f <= 64) return 4;
   if (f <= 512) return 5;
-  if (f <= 4096) return 6;
-  return 7;
+  if (f <= 2048) return 6;
+  if (f <= 4096) return 7;
+  return 8;
 }
 
 // error flag bits written by kernels into Workspace::d_err
@@ -88,7 +91,8 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 // LDS traffic between lanes of ONE wave: the LDS executes a wave's DS ops in order, so only the
 // compiler must be kept from reordering.
 __device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // compiler ordering only: no vmcnt drain
+  __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0)
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -102,10 +106,12 @@ __device__ __forceinline__ int next_pow2_clamped(int x, int lo, int hi) {
   return p;
 }
 
+__device__ __forceinline__ int log2_pow2(int p) { return 31 - __clz(p); }
+
 // ------------------------------------------------------------------------------------------------
 // LDS open-addressing hash (keys >= 0, EMPTY_KEY = -1), multiplicative hash, linear probing.
 // Returns the slot of `c`; *is_new is set when this call claimed the slot.  `size` is a power of
-// two >= 2 * (number of distinct keys), so a probe sequence always terminates; a bounded loop and an
+// two >= 1.5 * (number of distinct keys), so a probe sequence always terminates; a bounded loop and an
 // error flag guard against corrupt inputs instead of hanging the GPU.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int hash_insert(int* keys, int size, int shift, int c, bool* is_new, int* err) {
@@ -126,63 +132,64 @@ __device__ __forceinline__ int hash_insert(int* keys, int size, int shift, int c
   return 0;
 }
 
-__device__ __forceinline__ int log2_pow2(int p) { return 31 - __clz(p); }
-
 // ------------------------------------------------------------------------------------------------
 // K1  per-row product count + bin id + per-block bin histogram            (mindex2: gcomputeFlops)
-// One wave owns 64 consecutive rows and walks their A entries flattened over the lanes, so a row with
-// 4095 entries costs the same per entry as a row with 2.  256 threads = 4 waves = 256 rows / block.
+// One wave owns 64 consecutive rows.  Phase 1: every lane walks the first FL_SHORT entries of its own
+// row (87% of the rows of a power-law matrix end there).  Phase 2: rows that are longer are finished by
+// the whole wave, 64 entries per step, so a 4095-entry row costs 64 steps, not 4095.
 // ------------------------------------------------------------------------------------------------
 constexpr int K1_THREADS = 256;
+constexpr int FL_SHORT = 8;
 
 __global__ __launch_bounds__(K1_THREADS) void k_row_flops(
     int m, const int* __restrict__ IA, const int* __restrict__ JA, const int* __restrict__ IB,
     int* __restrict__ rowFlops, unsigned char* __restrict__ binId, int* __restrict__ blockHist,
-    unsigned long long* __restrict__ totalP, int* __restrict__ IC) {
-  __shared__ unsigned long long acc[K1_THREADS];
+    unsigned long long* __restrict__ blockP, int* __restrict__ IC) {
   __shared__ int hist[NBINS];
-  const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+  __shared__ unsigned long long psum;
+  const int tid = threadIdx.x, lane = lane_id();
   if (tid < NBINS) hist[tid] = 0;
-  acc[tid] = 0;
+  if (tid == 0) psum = 0;
   __syncthreads();
-  const int r0 = (blockIdx.x * (K1_THREADS / WAVE) + w) * WAVE;
-  const int r = r0 + lane;
-  const int rs = IA[min(r, m)];                      // start of my row (IA[m] past the end)
-  const int base = __builtin_amdgcn_readfirstlane(rs);
-  const int endAll = IA[min(r0 + WAVE, m)];
-  unsigned long long* wacc = acc + w * WAVE;
-  // uniform trip count: the lane shuffles below need every lane of the wave alive
-  const int rounds = (endAll - base + WAVE - 1) / WAVE;
-  for (int it = 0; it < rounds; ++it) {
-    const int idx = base + it * WAVE + lane;
-    const bool valid = idx < endAll;
-    int len = 0;
-    if (valid) { const int j = JA[idx]; len = IB[j + 1] - IB[j]; }
-    // local row = largest l with start_l <= idx  (binary search over the lanes' rs values)
-    int lo = 0;
-#pragma unroll
-    for (int step = 32; step >= 1; step >>= 1) {
-      const int cand = lo + step;
-      const int s = __shfl(rs, cand & 63, 64);
-      if (cand < WAVE && s <= idx) lo = cand;
-    }
-    if (valid && len) atomicAdd(&wacc[lo], (unsigned long long)len);
-  }
-  __syncthreads();
+  const int r = blockIdx.x * K1_THREADS + tid;
+  int rs = 0, re = 0;
+  if (r < m) { rs = IA[r]; re = IA[r + 1]; }
   unsigned long long f = 0;
+  {
+    int js[FL_SHORT];                                 // all JA loads first, then all IB loads: two round trips
+#pragma unroll
+    for (int t = 0; t < FL_SHORT; ++t) js[t] = rs + t < re ? JA[rs + t] : -1;
+#pragma unroll
+    for (int t = 0; t < FL_SHORT; ++t) if (js[t] >= 0) f += (unsigned)(IB[js[t] + 1] - IB[js[t]]);
+  }
+  // long rows: the wave takes them one by one
+  unsigned long long longMask = __ballot(re - rs > FL_SHORT);
+  while (longMask) {
+    const int src = __ffsll((long long)longMask) - 1;
+    longMask &= longMask - 1;
+    const int s = __shfl(rs, src, 64) + FL_SHORT, e = __shfl(re, src, 64);
+    unsigned long long part = 0;
+    for (int p = s + lane; p < e; p += WAVE) { const int j = JA[p]; part += (unsigned)(IB[j + 1] - IB[j]); }
+    part = wave_sum_u64(part);
+    if (lane == src) f += part;
+  }
   int b = -1;
   if (r < m) {
-    f = acc[tid];
     rowFlops[r] = f > 0x7fffffffULL ? 0x7fffffff : (int)f;
     b = bin_of(f);
     binId[r] = (unsigned char)b;
     if (b <= 1) IC[r] = b;                           // 0 products -> 0 entries, 1 product -> 1 entry
-    atomicAdd(&hist[b], 1);
+  }
+#pragma unroll
+  for (int q = 0; q < NBINS; ++q) {
+    const unsigned long long mk = __ballot(b == q);
+    if (lane == 0 && mk) atomicAdd(&hist[q], __popcll(mk));
   }
   const unsigned long long wsum = wave_sum_u64(f);
-  if (lane == 0 && wsum) atomicAdd(totalP, wsum);
+  if (lane == 0 && wsum) atomicAdd(&psum, wsum);
   __syncthreads();
   if (tid < NBINS) blockHist[blockIdx.x * NBINS + tid] = hist[tid];
+  if (tid == 0) blockP[blockIdx.x] = psum;      // no same-address global atomics: k_bin_scan sums these
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -190,12 +197,23 @@ __global__ __launch_bounds__(K1_THREADS) void k_row_flops(
 //     block writes its rows of each bin; binPtr[NBINS+1].  One 1024-thread block.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_bin_scan(int nblk, const int* __restrict__ blockHist,
-                                                    int* __restrict__ blockOff, int* __restrict__ binPtr) {
+                                                    int* __restrict__ blockOff, int* __restrict__ binPtr,
+                                                    const unsigned long long* __restrict__ blockP,
+                                                    unsigned long long* __restrict__ totalP) {
   __shared__ int wsum[16];
   __shared__ int running_s;
+  __shared__ unsigned long long ptot;
   const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
-  if (tid == 0) { running_s = 0; binPtr[0] = 0; }
+  if (tid == 0) { running_s = 0; binPtr[0] = 0; ptot = 0; }
   __syncthreads();
+  {
+    unsigned long long p = 0;
+    for (int b = tid; b < nblk; b += 1024) p += blockP[b];
+    p = wave_sum_u64(p);
+    if (lane == 0 && p) atomicAdd(&ptot, p);
+    __syncthreads();
+    if (tid == 0) *totalP = ptot;
+  }
   for (int b = 0; b < NBINS; ++b) {
     for (int t0 = 0; t0 < nblk; t0 += 1024) {
       const int blk = t0 + tid;
@@ -347,29 +365,186 @@ __global__ __launch_bounds__(256) void k_num_small(const int* __restrict__ binPt
 }
 
 // ------------------------------------------------------------------------------------------------
+// Rows with 17..64 products: 16 lanes per row (4 rows per wave), products flattened over the 16 lanes.
+// The old "A entries one after the other" walk costs three dependent memory round trips per A entry;
+// here a row costs three in total (JA -> IB -> JB/VB): the row's A entries are staged 16 at a time with a
+// 16-lane DPP scan of their B-row lengths, then 16-product rounds find their entry by a 4-step search.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int row16_incl_add(int v) {   // inclusive scan inside each 16-lane DPP row
+  v += SMF_DPP(v, 0x111, 0xf, 0);
+  v += SMF_DPP(v, 0x112, 0xf, 0);
+  v += SMF_DPP(v, 0x114, 0xf, 0);
+  v += SMF_DPP(v, 0x118, 0xf, 0);
+  return v;
+}
+
+struct G16Stage { int incl[16]; int off[16]; float aval[16]; };
+
+template <int U, bool NEED_VAL, class F>
+__device__ __forceinline__ void g16_walk(G16Stage& st, int gl, int as, int ae, const int* __restrict__ JA,
+                                         const float* __restrict__ VA, const int* __restrict__ IB,
+                                         const int* __restrict__ JB, const float* __restrict__ VB, F&& f) {
+  for (int chunk = as; chunk < ae; chunk += 16) {
+    const int ap = chunk + gl;
+    int len = 0, bs = 0;
+    float a = 0.f;
+    if (ap < ae) {
+      const int j = JA[ap];
+      bs = IB[j];
+      len = IB[j + 1] - bs;
+      if (NEED_VAL) a = VA[ap];
+    }
+    const int incl = row16_incl_add(len);
+    st.incl[gl] = incl;
+    st.off[gl] = bs - (incl - len);
+    if (NEED_VAL) st.aval[gl] = a;
+    wave_lds_sync();
+    const int T = st.incl[15];
+    for (int r0 = 0; r0 * 16 < T; r0 += U) {
+      int p[U], e[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { p[u] = (r0 + u) * 16 + gl; e[u] = 0; }
+#pragma unroll
+      for (int sft = 8; sft >= 1; sft >>= 1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int c = e[u] + sft;
+          e[u] = st.incl[c - 1] <= p[u] ? c : e[u];
+        }
+      }
+      int col[U];
+      float val[U];
+      bool act[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        act[u] = p[u] < T;
+        col[u] = 0;
+        val[u] = 0.f;
+        if (act[u]) {
+          const int jb = st.off[e[u]] + p[u];
+          col[u] = JB[jb];
+          if (NEED_VAL) val[u] = st.aval[e[u]] * VB[jb];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) f(act[u], col[u], val[u]);
+    }
+    wave_lds_sync();
+  }
+}
+
+template <int TBL, int U>
+__global__ __launch_bounds__(256) void k_sym_g16(const int* __restrict__ binPtr, int bin,
+                                                  const int* __restrict__ rowIds,
+                                                  const int* __restrict__ IA, const int* __restrict__ JA,
+                                                  const int* __restrict__ IB, const int* __restrict__ JB,
+                                                  const int* __restrict__ rowFlops, int* __restrict__ IC,
+                                                  int* __restrict__ err) {
+  __shared__ int keys[16][TBL];
+  __shared__ G16Stage st[16];
+  const int tid = threadIdx.x, g = tid >> 4, gl = tid & 15;
+  const int first = binPtr[bin], count = binPtr[bin + 1] - first;
+  const int iters = (count + 15) / 16;
+  for (int it = blockIdx.x; it < iters; it += gridDim.x) {
+    const int q = it * 16 + g;
+    const bool live = q < count;
+    const int row = live ? rowIds[first + q] : 0;
+    const int F = live ? rowFlops[row] : 1;
+    const int size = next_pow2_clamped(2 * F, 16, TBL);
+    const int shift = 32 - log2_pow2(size);
+    for (int i = gl; i < size; i += 16) keys[g][i] = EMPTY_KEY;
+    wave_lds_sync();
+    int mine = 0;
+    if (live) {
+      g16_walk<U, false>(st[g], gl, IA[row], IA[row + 1], JA, nullptr, IB, JB, nullptr, [&](bool active, int col, float) {
+        if (active) {
+          bool isnew;
+          hash_insert(keys[g], size, shift, col, &isnew, err);
+          mine += isnew ? 1 : 0;
+        }
+      });
+    }
+    mine = row16_incl_add(mine);
+    if (live && gl == 15) IC[row] = mine;
+    wave_lds_sync();
+  }
+}
+
+template <int TBL, int U>
+__global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr, int bin,
+                                                  const int* __restrict__ rowIds,
+                                                  const int* __restrict__ IA, const int* __restrict__ JA,
+                                                  const float* __restrict__ VA,
+                                                  const int* __restrict__ IB, const int* __restrict__ JB,
+                                                  const float* __restrict__ VB,
+                                                  const int* __restrict__ IC, int* __restrict__ JC,
+                                                  float* __restrict__ C, int* __restrict__ err) {
+  __shared__ int keys[16][TBL];
+  __shared__ float vals[16][TBL];
+  __shared__ G16Stage st[16];
+  const int tid = threadIdx.x, g = tid >> 4, gl = tid & 15;
+  const int first = binPtr[bin], count = binPtr[bin + 1] - first;
+  const int iters = (count + 15) / 16;
+  for (int it = blockIdx.x; it < iters; it += gridDim.x) {
+    const int q = it * 16 + g;
+    const bool live = q < count;
+    const int row = live ? rowIds[first + q] : 0;
+    const int off = live ? IC[row] : 0;
+    const int want = live ? IC[row + 1] - off : 0;
+    const int size = next_pow2_clamped(2 * want, 16, TBL);
+    const int shift = 32 - log2_pow2(size);
+    for (int i = gl; i < size; i += 16) { keys[g][i] = EMPTY_KEY; vals[g][i] = 0.f; }
+    wave_lds_sync();
+    if (live) {
+      g16_walk<U, true>(st[g], gl, IA[row], IA[row + 1], JA, VA, IB, JB, VB, [&](bool active, int col, float v) {
+        if (active) {
+          bool isnew;
+          const int s = hash_insert(keys[g], size, shift, col, &isnew, err);
+          atomicAdd(&vals[g][s], v);
+        }
+      });
+    }
+    wave_lds_sync();
+    int written = 0;
+    for (int i0 = 0; i0 < size; i0 += 16) {
+      const int i = i0 + gl;
+      const int kx = keys[g][i];
+      const bool occ = live && kx != EMPTY_KEY;
+      const unsigned long long mk = __ballot(occ);
+      const unsigned gm = (unsigned)(mk >> (lane_id() - gl)) & 0xffffu;
+      const int rank = __popc(gm & ((1u << gl) - 1u));
+      if (occ) { JC[off + written + rank] = kx; C[off + written + rank] = vals[g][i]; }
+      written += __popc(gm);
+    }
+    if (live && gl == 0 && written != want) atomicOr(err, ERRF_COUNT_MISMATCH);
+    wave_lds_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Flattened product walk of ONE C row by a block of NW waves.
 // A entries are staged in LDS in chunks of 64*NW (one per thread) together with the inclusive scan
-// of their B-row lengths; then every wave takes rounds of 64 consecutive products.  For a round the
-// wave finds the first owning A entry with two 64-ary ballot searches, lets the <=64 entries that start
-// inside the round mark their first product, and a DPP max-scan spreads the owner to the products
-// that follow.  f(active, jbIndex, aValue) is called in wave-uniform control flow.
+// of their B-row lengths; the staged arrays are read-only until the next chunk.  Every wave then takes
+// rounds of 64 consecutive products, U rounds per trip so that U gathers of B are in flight per wave.
+// A lane finds the A entry that owns its product with a branch-free binary search over the scan in LDS
+// (log2(64*NW) dependent ds_reads, the U searches of a trip interleave): no ballots, no fences, no
+// divergence in the walk.  f(active, col, val) is called in wave-uniform control flow (val = a*b).
 // ------------------------------------------------------------------------------------------------
-template <int NW>
+template <int NW, int U>
 struct RowStage {
-  int incl[WAVE * NW];     // inclusive scan of B-row lengths of the staged A entries
+  int incl[WAVE * NW];     // inclusive scan of B-row lengths of the staged A entries (T beyond the row)
   int off[WAVE * NW];      // IB[j] - exclusive scan: product p of the chunk lives at JB[off + p]
   float aval[WAVE * NW];
-  int marks[NW][WAVE];
   int wsum[NW];
 };
 
-template <int NW, bool NEED_VAL, class F>
-__device__ __forceinline__ void for_each_product(RowStage<NW>& st, int as, int ae,
+template <int NW, int U, bool NEED_VAL, class F>
+__device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, int ae,
                                                  const int* __restrict__ JA, const float* __restrict__ VA,
-                                                 const int* __restrict__ IB, F&& f) {
+                                                 const int* __restrict__ IB, const int* __restrict__ JB,
+                                                 const float* __restrict__ VB, F&& f) {
   constexpr int K = WAVE * NW;
   const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
-  st.marks[w][lane] = 0;
   for (int chunk = as; chunk < ae; chunk += K) {
     // ---- stage
     const int ap = chunk + tid;
@@ -394,83 +569,135 @@ __device__ __forceinline__ void for_each_product(RowStage<NW>& st, int as, int a
     if (NEED_VAL) st.aval[tid] = a;
     __syncthreads();
     const int T = st.incl[K - 1];
-    const int nk = min(K, ae - chunk);
-    // ---- rounds
-    for (int base = w * WAVE; base < T; base += K) {
-      const int roundEnd = min(base + WAVE, T);
-      int grp = 0;
-      if (NW > 1) {
-        const int v1 = lane < NW ? st.incl[lane * WAVE + 63] : 0x7fffffff;
-        grp = __popcll(__ballot(v1 <= base));
-      }
-      const int v2 = st.incl[grp * WAVE + lane];
-      const int k0 = grp * WAVE + __popcll(__ballot(v2 <= base));   // first entry with incl > base
-      for (int eb = k0;; eb += WAVE) {
-        const int e = eb + lane;
-        if (e < nk) {
-          const int s = e == 0 ? 0 : st.incl[e - 1];
-          const int en = st.incl[e];
-          if (en > s && s < roundEnd && en > base) st.marks[w][max(s, base) - base] = e - k0;
+    const int nrounds = (T + WAVE - 1) / WAVE;
+    // ---- rounds: wave w owns rounds w, w+NW, ...; U of them per trip
+    for (int r0 = w; r0 < nrounds; r0 += NW * U) {
+      int p[U], e[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { p[u] = (r0 + u * NW) * WAVE + lane; e[u] = 0; }
+      // first entry with incl > p, all U searches in lock step
+#pragma unroll
+      for (int sft = K / 2; sft >= 1; sft >>= 1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int c = e[u] + sft;
+          e[u] = st.incl[c - 1] <= p[u] ? c : e[u];
         }
-        const int lastc = min(eb + WAVE - 1, nk - 1);
-        if (st.incl[lastc] >= roundEnd) break;
       }
-      wave_lds_sync();
-      const int mv = st.marks[w][lane];
-      st.marks[w][lane] = 0;
-      const int owner = k0 + wave_incl_max(mv);
-      const int p = base + lane;
-      const bool active = p < T;
-      const int oi = active ? owner : k0;
-      const int jb = st.off[oi] + p;
-      const float av = NEED_VAL ? st.aval[oi] : 0.f;
-      f(active, jb, av);
-      wave_lds_sync();
+      int col[U];
+      float val[U];
+      bool act[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        act[u] = p[u] < T;
+        col[u] = 0;
+        val[u] = 0.f;
+        if (act[u]) {
+          const int jb = st.off[e[u]] + p[u];
+          col[u] = JB[jb];
+          if (NEED_VAL) val[u] = st.aval[e[u]] * VB[jb];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) f(act[u], col[u], val[u]);
     }
     __syncthreads();
   }
 }
 
+// dynamic row scheduling for block-per-row kernels: rows of a bin differ by up to 8x in work, a static
+// round-robin leaves the CUs with the light rows idle.  One agent-scope atomic per row (guide: "dequeue",
+// ~0.3-1 us, overlapped with the previous row's tail by fetching one row ahead).
+__device__ __forceinline__ int next_row(int* ctr, int* slot) {
+  if (threadIdx.x == 0) *slot = atomicAdd(ctr, 1);
+  __syncthreads();
+  const int q = *slot;
+  __syncthreads();
+  return q;
+}
+
+// per-row metadata, fetched one row ahead of use so that the dependent rowIds -> IA/IC loads of the
+// next row overlap the current row's work
+struct RowMeta { int row, as, ae, x0, x1; };
+
+__device__ __forceinline__ RowMeta load_meta_sym(const int* rows, int q, int count, const int* IA, const int* rowFlops) {
+  RowMeta mtd{0, 0, 0, 0, 0};
+  if (q < count) { mtd.row = rows[q]; mtd.as = IA[mtd.row]; mtd.ae = IA[mtd.row + 1]; mtd.x0 = rowFlops[mtd.row]; }
+  return mtd;
+}
+__device__ __forceinline__ RowMeta load_meta_num(const int* rows, int q, int count, const int* IA, const int* IC) {
+  RowMeta mtd{0, 0, 0, 0, 0};
+  if (q < count) { mtd.row = rows[q]; mtd.as = IA[mtd.row]; mtd.ae = IA[mtd.row + 1]; mtd.x0 = IC[mtd.row]; mtd.x1 = IC[mtd.row + 1]; }
+  return mtd;
+}
+
+// block-wide exclusive scan of one int per thread (NW waves); returns exclusive value, *total = sum
+template <int NW>
+__device__ __forceinline__ int block_excl_scan(int v, int* red, int* total) {
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  const int incl = wave_incl_add(v);
+  if (NW == 1) { *total = __builtin_amdgcn_readlane(incl, 63); return incl - v; }
+  __syncthreads();
+  if (lane == 63) red[w] = incl;
+  __syncthreads();
+  int woff = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) { const int s = red[i]; tot += s; if (i < w) woff += s; }
+  *total = tot;
+  return woff + incl - v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Medium rows (65..4096 products): one block of NW waves per row, LDS key table (symbolic) or
-// key+value table with an insertion-ordered slot list (numeric).
+// key+value table compacted by a table sweep (numeric).
 // ------------------------------------------------------------------------------------------------
-template <int NW, int TBL>
+template <int NW, int TBL, int U>
 __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ binPtr, int bin,
                                                          const int* __restrict__ rowIds,
                                                          const int* __restrict__ IA, const int* __restrict__ JA,
                                                          const int* __restrict__ IB, const int* __restrict__ JB,
                                                          const int* __restrict__ rowFlops, int* __restrict__ IC,
-                                                         int* __restrict__ err) {
+                                                         int* __restrict__ err, int* __restrict__ qctr) {
   __shared__ int keys[TBL];
-  __shared__ RowStage<NW> st;
+  __shared__ RowStage<NW, U> st;
   __shared__ int cnt_s;
+  __shared__ int qslot;
   const int tid = threadIdx.x, lane = lane_id();
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
-  for (int q = blockIdx.x; q < count; q += gridDim.x) {
-    const int row = rowIds[first + q];
-    const int size = next_pow2_clamped(2 * rowFlops[row], 64, TBL);
+  const int* rows = rowIds + first;
+  int q = NW > 1 ? next_row(qctr, &qslot) : (int)blockIdx.x;
+  RowMeta cur = load_meta_sym(rows, q, count, IA, rowFlops);
+  while (q < count) {
+    const int qn = NW > 1 ? next_row(qctr, &qslot) : q + (int)gridDim.x;
+    const RowMeta nxt = load_meta_sym(rows, qn, count, IA, rowFlops);
+    const int size = next_pow2_clamped(2 * cur.x0, 64, TBL);
     const int shift = 32 - log2_pow2(size);
     for (int i = tid; i < size; i += WAVE * NW) keys[i] = EMPTY_KEY;
     if (tid == 0) cnt_s = 0;
     __syncthreads();
     int mine = 0;
-    for_each_product<NW, false>(st, IA[row], IA[row + 1], JA, nullptr, IB, [&](bool active, int jb, float) {
+    for_each_product<NW, U, false>(st, cur.as, cur.ae, JA, nullptr, IB, JB, nullptr, [&](bool active, int col, float) {
       if (active) {
         bool isnew;
-        hash_insert(keys, size, shift, JB[jb], &isnew, err);
+        hash_insert(keys, size, shift, col, &isnew, err);
         mine += isnew ? 1 : 0;
       }
     });
     const int ws = wave_sum(mine);
-    if (lane == 0 && ws) atomicAdd(&cnt_s, ws);
+    if (NW == 1) {
+      if (lane == 0) IC[cur.row] = ws;
+    } else {
+      if (lane == 0 && ws) atomicAdd(&cnt_s, ws);
+      __syncthreads();
+      if (tid == 0) IC[cur.row] = cnt_s;
+    }
     __syncthreads();
-    if (tid == 0) IC[row] = cnt_s;
-    __syncthreads();
+    cur = nxt;
+    q = qn;
   }
 }
 
-template <int NW, int TBL>
+template <int NW, int TBL, int U>
 __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ binPtr, int bin,
                                                          const int* __restrict__ rowIds,
                                                          const int* __restrict__ IA, const int* __restrict__ JA,
@@ -478,75 +705,97 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
                                                          const int* __restrict__ IB, const int* __restrict__ JB,
                                                          const float* __restrict__ VB,
                                                          const int* __restrict__ IC, int* __restrict__ JC,
-                                                         float* __restrict__ C, int* __restrict__ err) {
+                                                         float* __restrict__ C, int* __restrict__ err,
+                                                         int* __restrict__ qctr) {
   __shared__ int keys[TBL];
   __shared__ float vals[TBL];
-  __shared__ unsigned short slots[TBL / 2];   // slot of the i-th distinct column, in claim order
-  __shared__ RowStage<NW> st;
-  __shared__ int cnt_s;
-  const int tid = threadIdx.x, lane = lane_id();
+  __shared__ RowStage<NW, U> st;
+  __shared__ int red[NW];
+  __shared__ int qslot;
+  const int tid = threadIdx.x;
+  constexpr int T = WAVE * NW;
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
-  for (int q = blockIdx.x; q < count; q += gridDim.x) {
-    const int row = rowIds[first + q];
-    const int off = IC[row];
-    const int want = IC[row + 1] - off;                 // exact distinct count from the symbolic pass
-    const int size = next_pow2_clamped(2 * want, 64, TBL);
+  const int* rows = rowIds + first;
+  int q = NW > 1 ? next_row(qctr, &qslot) : (int)blockIdx.x;
+  RowMeta cur = load_meta_num(rows, q, count, IA, IC);
+  while (q < count) {
+    const int qn = NW > 1 ? next_row(qctr, &qslot) : q + (int)gridDim.x;
+    const RowMeta nxt = load_meta_num(rows, qn, count, IA, IC);
+    const int off = cur.x0;
+    const int want = cur.x1 - off;                      // exact distinct count from the symbolic pass
+    const int size = next_pow2_clamped(2 * want, T > 64 ? T : 64, TBL);
     const int shift = 32 - log2_pow2(size);
-    for (int i = tid; i < size; i += WAVE * NW) { keys[i] = EMPTY_KEY; vals[i] = 0.f; }
-    if (tid == 0) cnt_s = 0;
+    for (int i = tid; i < size; i += T) { keys[i] = EMPTY_KEY; vals[i] = 0.f; }
     __syncthreads();
-    for_each_product<NW, true>(st, IA[row], IA[row + 1], JA, VA, IB, [&](bool active, int jb, float a) {
-      bool isnew = false;
-      int s = 0;
+    for_each_product<NW, U, true>(st, cur.as, cur.ae, JA, VA, IB, JB, VB, [&](bool active, int col, float v) {
       if (active) {
-        s = hash_insert(keys, size, shift, JB[jb], &isnew, err);
-        atomicAdd(&vals[s], a * VB[jb]);
-      }
-      const unsigned long long nm = __ballot(isnew);
-      if (nm) {
-        int basei = 0;
-        if (lane == 0) basei = atomicAdd(&cnt_s, __popcll(nm));
-        basei = __builtin_amdgcn_readfirstlane(basei);
-        if (isnew) slots[min(basei + mask_rank(nm), TBL / 2 - 1)] = (unsigned short)s;
+        bool isnew;
+        const int s = hash_insert(keys, size, shift, col, &isnew, err);
+        atomicAdd(&vals[s], v);
       }
     });
-    __syncthreads();
-    const int n = cnt_s;
-    if (tid == 0 && n != want) atomicOr(err, ERRF_COUNT_MISMATCH);
-    for (int i = tid; i < min(n, want); i += WAVE * NW) {
-      const int s = slots[i];
-      JC[off + i] = keys[s];
-      C[off + i] = vals[s];
+    // compaction: wave w sweeps the contiguous slots [w*per, w*per+per) 64 at a time, so that a wave's stores
+    // land on consecutive output positions
+    const int per = size / NW;
+    const int lane = lane_id(), w = tid >> 6;
+    int mine = 0;
+    for (int i = lane; i < per; i += WAVE) mine += keys[w * per + i] != EMPTY_KEY;
+    int wtot = wave_sum(mine);
+    int total;
+    int pos = off + block_excl_scan<NW>(lane == 0 ? wtot : 0, red, &total);
+    pos = __builtin_amdgcn_readfirstlane(pos);
+    for (int i0 = 0; i0 < per; i0 += WAVE) {
+      const int sl = w * per + i0 + lane;
+      const int kx = keys[sl];
+      const bool occ = kx != EMPTY_KEY;
+      const unsigned long long mk = __ballot(occ);
+      if (occ) { const int o = pos + mask_rank(mk); JC[o] = kx; C[o] = vals[sl]; }
+      pos += __popcll(mk);
     }
+    if (tid == 0 && total != want) atomicOr(err, ERRF_COUNT_MISMATCH);
     __syncthreads();
+    cur = nxt;
+    q = qn;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Big rows (> 4096 products): one 1024-thread block per row, column window of BIG_WC columns held
-// as an LDS bitmap.  Symbolic = popcount.  Numeric = popcount ranks give every column its final
-// position, values accumulate in an LDS float array addressed by rank (no probing, sorted output);
-// rows with more distinct columns than BIG_CAP take several rank passes, matrices with more than
-// BIG_WC columns several column windows.
+// Big rows (> 4096 products): one 1024-thread block per row.
+//   symbolic : LDS bitmap over a window of SYM_WC columns, popcount           (any n, 1 window up to 1M cols)
+//   numeric A: n <= BIG_WC: bitmap (saved by the symbolic pass when the workspace has room, rebuilt
+//              otherwise) + popcount ranks give every column its final position; values accumulate in an
+//              LDS float array addressed by rank (no probing, sorted output)
+//   numeric B: any n: 128 KB LDS hash table; rows with more distinct columns than one table holds take
+//              several passes, each pass owning the columns of one hash class
 // ------------------------------------------------------------------------------------------------
 constexpr int BIG_NW = 16;
 constexpr int BIG_THREADS = BIG_NW * WAVE;
-constexpr int BIG_WC = 262144;                 // columns per window (32 KB bitmap)
+constexpr int BIG_U = 4;
+constexpr int SYM_WC = 1 << 20;                // columns per symbolic window (128 KB bitmap)
+constexpr int SYM_WORDS = SYM_WC / 32;
+constexpr int BIG_WC = 262144;                 // columns covered by the rank kernel (32 KB bitmap)
 constexpr int BIG_WORDS = BIG_WC / 32;         // 8192
 constexpr int BIG_WPT = BIG_WORDS / BIG_THREADS;  // 8 words per thread
 constexpr int BIG_CAP = 18432;                 // float accumulators per rank pass (72 KB)
+constexpr int BH_SLOTS = 16384;                // hash kernel: 64 KB keys + 64 KB values
+constexpr int BH_CAP = 9216;                   // distinct columns per hash pass (load <= 0.56 + partition skew)
 
 struct BigSymShared {
-  unsigned bitmap[BIG_WORDS];
-  RowStage<BIG_NW> st;
+  unsigned bitmap[SYM_WORDS];
+  RowStage<BIG_NW, BIG_U> st;
   int red[BIG_NW];
 };
-
 struct BigNumShared {
   unsigned bitmap[BIG_WORDS];
   int prefix[BIG_WORDS];
   float acc[BIG_CAP];
-  RowStage<BIG_NW> st;
+  RowStage<BIG_NW, BIG_U> st;
+  int red[BIG_NW];
+};
+struct BigHashShared {
+  int keys[BH_SLOTS];
+  float vals[BH_SLOTS];
+  RowStage<BIG_NW, BIG_U> st;
   int red[BIG_NW];
 };
 
@@ -561,32 +810,39 @@ __device__ __forceinline__ int block_sum_16(int v, int* red) {
   return tot;
 }
 
+// saveBitmaps: device buffer of saveCap row slots x BIG_WORDS words (may be null / 0); only used when n <= BIG_WC
 __global__ __launch_bounds__(BIG_THREADS) void k_sym_big(const int* __restrict__ binPtr, int bin,
                                                          const int* __restrict__ rowIds,
                                                          const int* __restrict__ IA, const int* __restrict__ JA,
                                                          const int* __restrict__ IB, const int* __restrict__ JB,
-                                                         int n, int* __restrict__ IC) {
+                                                         int n, int* __restrict__ IC,
+                                                         unsigned* __restrict__ saveBitmaps, int saveCap,
+                                                         int* __restrict__ qctr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   BigSymShared& sh = *reinterpret_cast<BigSymShared*>(smem_raw);
   const int tid = threadIdx.x;
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
-  for (int q = blockIdx.x; q < count; q += gridDim.x) {
+  for (int q = next_row(qctr, &sh.red[0]); q < count; q = next_row(qctr, &sh.red[0])) {
     const int row = rowIds[first + q];
     const int as = IA[row], ae = IA[row + 1];
     int total = 0;
-    for (int w0 = 0; w0 < n; w0 += BIG_WC) {
-      const int wc = min(BIG_WC, n - w0);
+    for (int w0 = 0; w0 < n; w0 += SYM_WC) {
+      const int wc = min(SYM_WC, n - w0);
       const int words = (wc + 31) >> 5;
       for (int i = tid; i < words; i += BIG_THREADS) sh.bitmap[i] = 0u;
       __syncthreads();
-      for_each_product<BIG_NW, false>(sh.st, as, ae, JA, nullptr, IB, [&](bool active, int jb, float) {
+      for_each_product<BIG_NW, BIG_U, false>(sh.st, as, ae, JA, nullptr, IB, JB, nullptr, [&](bool active, int col, float) {
         if (active) {
-          const int c = JB[jb] - w0;
+          const int c = col - w0;
           if ((unsigned)c < (unsigned)wc) atomicOr(&sh.bitmap[c >> 5], 1u << (c & 31));
         }
       });
       int mine = 0;
       for (int i = tid; i < words; i += BIG_THREADS) mine += __popc(sh.bitmap[i]);
+      if (n <= BIG_WC && q < saveCap) {
+        unsigned* dst = saveBitmaps + (size_t)q * BIG_WORDS;
+        for (int i = tid; i < BIG_WORDS; i += BIG_THREADS) dst[i] = i < words ? sh.bitmap[i] : 0u;
+      }
       total += block_sum_16(mine, sh.red);
       __syncthreads();
     }
@@ -594,6 +850,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sym_big(const int* __restrict__
   }
 }
 
+// numeric A (n <= BIG_WC): rank kernel
 __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__ binPtr, int bin,
                                                          const int* __restrict__ rowIds,
                                                          const int* __restrict__ IA, const int* __restrict__ JA,
@@ -601,75 +858,138 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
                                                          const int* __restrict__ IB, const int* __restrict__ JB,
                                                          const float* __restrict__ VB, int n,
                                                          const int* __restrict__ IC, int* __restrict__ JC,
-                                                         float* __restrict__ C, int* __restrict__ err) {
+                                                         float* __restrict__ C, int* __restrict__ err,
+                                                         const unsigned* __restrict__ savedBitmaps, int savedCap,
+                                                         int* __restrict__ qctr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   BigNumShared& sh = *reinterpret_cast<BigNumShared*>(smem_raw);
   const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
-  for (int q = blockIdx.x; q < count; q += gridDim.x) {
+  for (int q = next_row(qctr, &sh.red[0]); q < count; q = next_row(qctr, &sh.red[0])) {
+    const int row = rowIds[first + q];
+    const int as = IA[row], ae = IA[row + 1];
+    const int outBase = IC[row];
+    const int outEnd = IC[row + 1];
+    // which columns occur: reload the symbolic pass's bitmap, or rebuild it
+    if (q < savedCap) {
+      const unsigned* src = savedBitmaps + (size_t)q * BIG_WORDS;
+      for (int i = tid; i < BIG_WORDS; i += BIG_THREADS) sh.bitmap[i] = src[i];
+      __syncthreads();
+    } else {
+      for (int i = tid; i < BIG_WORDS; i += BIG_THREADS) sh.bitmap[i] = 0u;
+      __syncthreads();
+      for_each_product<BIG_NW, BIG_U, false>(sh.st, as, ae, JA, nullptr, IB, JB, nullptr, [&](bool active, int col, float) {
+        if (active && (unsigned)col < (unsigned)n) atomicOr(&sh.bitmap[col >> 5], 1u << (col & 31));
+      });
+    }
+    // exclusive popcount prefix over the words: thread t owns words [t*WPT, t*WPT+WPT)
+    int loc[BIG_WPT];
+    int mine = 0;
+#pragma unroll
+    for (int i = 0; i < BIG_WPT; ++i) { loc[i] = mine; mine += __popc(sh.bitmap[tid * BIG_WPT + i]); }
+    const int incl = wave_incl_add(mine);
+    __syncthreads();
+    if (lane == 63) sh.red[w] = incl;
+    __syncthreads();
+    int woff = 0, cntw = 0;
+    for (int i = 0; i < BIG_NW; ++i) { const int s = sh.red[i]; cntw += s; if (i < w) woff += s; }
+    const int texcl = woff + incl - mine;
+#pragma unroll
+    for (int i = 0; i < BIG_WPT; ++i) sh.prefix[tid * BIG_WPT + i] = texcl + loc[i];
+    __syncthreads();
+    if (outBase + cntw != outEnd) { if (tid == 0) atomicOr(err, ERRF_COUNT_MISMATCH); cntw = min(cntw, max(0, outEnd - outBase)); }
+    // BIG_CAP ranks at a time: column indices first (already sorted; scattered into LDS by rank, then stored
+    // coalesced), then the values accumulated by rank
+    int* accI = reinterpret_cast<int*>(sh.acc);
+    for (int lo = 0; lo < cntw; lo += BIG_CAP) {
+      const int span = min(BIG_CAP, cntw - lo);
+#pragma unroll
+      for (int i = 0; i < BIG_WPT; ++i) {
+        unsigned bits = sh.bitmap[tid * BIG_WPT + i];
+        int pos = texcl + loc[i] - lo;
+        const int cbase = (tid * BIG_WPT + i) * 32;
+        while (bits) {
+          const int b = __ffs(bits) - 1;
+          bits &= bits - 1;
+          if ((unsigned)pos < (unsigned)span) accI[pos] = cbase + b;
+          ++pos;
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < span; i += BIG_THREADS) JC[outBase + lo + i] = accI[i];
+      __syncthreads();
+      for (int i = tid; i < span; i += BIG_THREADS) sh.acc[i] = 0.f;
+      __syncthreads();
+      for_each_product<BIG_NW, BIG_U, true>(sh.st, as, ae, JA, VA, IB, JB, VB, [&](bool active, int col, float v) {
+        if (active && (unsigned)col < (unsigned)n) {
+          const int wi = col >> 5;
+          const int rk = sh.prefix[wi] + __popc(sh.bitmap[wi] & ((1u << (col & 31)) - 1u)) - lo;
+          if ((unsigned)rk < (unsigned)span) atomicAdd(&sh.acc[rk], v);
+        }
+      });
+      for (int i = tid; i < span; i += BIG_THREADS) C[outBase + lo + i] = sh.acc[i];
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+}
+
+// numeric B (any n): multi-pass LDS hash
+__global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restrict__ binPtr, int bin,
+                                                             const int* __restrict__ rowIds,
+                                                             const int* __restrict__ IA, const int* __restrict__ JA,
+                                                             const float* __restrict__ VA,
+                                                             const int* __restrict__ IB, const int* __restrict__ JB,
+                                                             const float* __restrict__ VB,
+                                                             const int* __restrict__ IC, int* __restrict__ JC,
+                                                             float* __restrict__ C, int* __restrict__ err,
+                                                             int* __restrict__ qctr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  BigHashShared& sh = *reinterpret_cast<BigHashShared*>(smem_raw);
+  const int tid = threadIdx.x;
+  const int first = binPtr[bin], count = binPtr[bin + 1] - first;
+  for (int q = next_row(qctr, &sh.red[0]); q < count; q = next_row(qctr, &sh.red[0])) {
     const int row = rowIds[first + q];
     const int as = IA[row], ae = IA[row + 1];
     int outBase = IC[row];
     const int outEnd = IC[row + 1];
-    for (int w0 = 0; w0 < n; w0 += BIG_WC) {
-      const int wc = min(BIG_WC, n - w0);
-      for (int i = tid; i < BIG_WORDS; i += BIG_THREADS) sh.bitmap[i] = 0u;
+    const int want = outEnd - outBase;
+    const unsigned npass = (unsigned)((want + BH_CAP - 1) / BH_CAP);
+    const int size = npass > 1 ? BH_SLOTS : next_pow2_clamped(2 * want, BIG_THREADS, BH_SLOTS);
+    const int shift = 32 - log2_pow2(size);
+    const int per = size / BIG_NW;
+    for (unsigned pass = 0; pass < npass; ++pass) {
+      for (int i = tid; i < size; i += BIG_THREADS) { sh.keys[i] = EMPTY_KEY; sh.vals[i] = 0.f; }
       __syncthreads();
-      // pass 1: which columns of this window occur
-      for_each_product<BIG_NW, false>(sh.st, as, ae, JA, nullptr, IB, [&](bool active, int jb, float) {
+      for_each_product<BIG_NW, BIG_U, true>(sh.st, as, ae, JA, VA, IB, JB, VB, [&](bool active, int col, float v) {
         if (active) {
-          const int c = JB[jb] - w0;
-          if ((unsigned)c < (unsigned)wc) atomicOr(&sh.bitmap[c >> 5], 1u << (c & 31));
+          // hash class of a column: bits of a second multiplicative hash, independent of the slot hash
+          const bool minePass = npass == 1 || (((unsigned)col * 0x85ebca6bu) >> 12) % npass == pass;
+          if (minePass) {
+            bool isnew;
+            const int s = hash_insert(sh.keys, size, shift, col, &isnew, err);
+            atomicAdd(&sh.vals[s], v);
+          }
         }
       });
-      // exclusive popcount prefix over the words: thread t owns words [t*WPT, t*WPT+WPT)
-      int loc[BIG_WPT];
+      // compaction: wave w sweeps slots [w*per, w*per+per), 64 per step -> coalesced stores
+      const int lane = lane_id(), w = tid >> 6;
       int mine = 0;
-#pragma unroll
-      for (int i = 0; i < BIG_WPT; ++i) { loc[i] = mine; mine += __popc(sh.bitmap[tid * BIG_WPT + i]); }
-      const int incl = wave_incl_add(mine);
-      __syncthreads();
-      if (lane == 63) sh.red[w] = incl;
-      __syncthreads();
-      int woff = 0, cntw = 0;
-      for (int i = 0; i < BIG_NW; ++i) { const int s = sh.red[i]; cntw += s; if (i < w) woff += s; }
-      const int texcl = woff + incl - mine;
-#pragma unroll
-      for (int i = 0; i < BIG_WPT; ++i) sh.prefix[tid * BIG_WPT + i] = texcl + loc[i];
-      __syncthreads();
-      if (outBase + cntw > outEnd) { if (tid == 0) atomicOr(err, ERRF_COUNT_MISMATCH); cntw = max(0, outEnd - outBase); }
-      // column indices, already sorted
-#pragma unroll
-      for (int i = 0; i < BIG_WPT; ++i) {
-        unsigned bits = sh.bitmap[tid * BIG_WPT + i];
-        int pos = texcl + loc[i];
-        const int cbase = w0 + (tid * BIG_WPT + i) * 32;
-        while (bits) {
-          const int b = __ffs(bits) - 1;
-          bits &= bits - 1;
-          if (pos < cntw) JC[outBase + pos] = cbase + b;
-          ++pos;
-        }
+      for (int i = lane; i < per; i += WAVE) mine += sh.keys[w * per + i] != EMPTY_KEY;
+      const int wtot = wave_sum(mine);
+      int total;
+      int pos = outBase + block_excl_scan<BIG_NW>(lane == 0 ? wtot : 0, sh.red, &total);
+      pos = __builtin_amdgcn_readfirstlane(pos);
+      for (int i0 = 0; i0 < per; i0 += WAVE) {
+        const int sl = w * per + i0 + lane;
+        const int kx = sh.keys[sl];
+        const bool occ = kx != EMPTY_KEY;
+        const unsigned long long mk = __ballot(occ);
+        if (occ) { const int o = pos + mask_rank(mk); if (o < outEnd) { JC[o] = kx; C[o] = sh.vals[sl]; } }
+        pos += __popcll(mk);
       }
-      // pass 2..: accumulate values by rank, BIG_CAP ranks at a time
-      for (int lo = 0; lo < cntw; lo += BIG_CAP) {
-        const int span = min(BIG_CAP, cntw - lo);
-        for (int i = tid; i < span; i += BIG_THREADS) sh.acc[i] = 0.f;
-        __syncthreads();
-        for_each_product<BIG_NW, true>(sh.st, as, ae, JA, VA, IB, [&](bool active, int jb, float a) {
-          if (active) {
-            const int c = JB[jb] - w0;
-            if ((unsigned)c < (unsigned)wc) {
-              const int wi = c >> 5;
-              const int rk = sh.prefix[wi] + __popc(sh.bitmap[wi] & ((1u << (c & 31)) - 1u)) - lo;
-              if ((unsigned)rk < (unsigned)span) atomicAdd(&sh.acc[rk], a * VB[jb]);
-            }
-          }
-        });
-        for (int i = tid; i < span; i += BIG_THREADS) C[outBase + lo + i] = sh.acc[i];
-        __syncthreads();
-      }
-      outBase += cntw;
+      outBase += total;
+      __syncthreads();
     }
     if (tid == 0 && outBase != outEnd) atomicOr(err, ERRF_COUNT_MISMATCH);
     __syncthreads();
@@ -701,7 +1021,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_sums(int m, const in
 
 __global__ __launch_bounds__(1024) void k_scan_tiles(int ntiles, unsigned long long* __restrict__ tileSum,
                                                       unsigned long long* __restrict__ total) {
-  // serial over tiles in chunks of 1024 (ntiles is m/4096: small)
   __shared__ unsigned long long wsum[16];
   __shared__ unsigned long long running;
   const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
@@ -760,12 +1079,8 @@ __global__ void k_gather_flops(int m, const int* __restrict__ rowIds, const int*
   if (q < m) out[q] = rowFlops[rowIds[q]];
 }
 
-// saturating inclusive scan companion: dst[i+1] = min(INT_MAX, excl[i] + v[i]) is produced on the host side
-// by scanning in 64-bit; see spgemm_hip.hip (classify is an API-only path, not part of the hot loop).
-
 // CSR::makeOrdered on the device (nlibs/CSR.cc:73-86): one block per row, bitonic sort in LDS for rows
-// of <= SORT_MAX entries.  Longer rows only come out of k_num_big, which emits them sorted already: they
-// are checked and, if some caller hands in a long unsorted row, sorted by odd-even transposition in
+// of <= SORT_MAX entries.  Longer rows are checked and, if unsorted, sorted by odd-even transposition in
 // global memory (slow, correct).  Used by tests/drivers, not by the timed path.
 constexpr int SORT_MAX = 4096;
 __global__ __launch_bounds__(256) void k_sort_rows(int m, const int* __restrict__ IC, int* __restrict__ JC,
@@ -819,7 +1134,7 @@ __global__ __launch_bounds__(256) void k_sort_rows(int m, const int* __restrict_
   }
 }
 
-// self-test of the DPP scans / mask ranks against serial results computed by lane 0
+// self-test of the DPP scans / mask ranks against serial results computed by every lane
 __global__ void k_selftest(const int* __restrict__ in, int* __restrict__ bad) {
   __shared__ int buf[WAVE];
   const int lane = lane_id();

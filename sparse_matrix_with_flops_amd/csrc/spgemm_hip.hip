@@ -16,6 +16,8 @@
 
 using namespace smf;
 
+static_assert(NBINS == SPGEMM_NBINS, "bin count of the kernels and of the C ABI differ");
+
 // ------------------------------------------------------------------------------------------------
 // errors
 // ------------------------------------------------------------------------------------------------
@@ -113,10 +115,11 @@ DevPool& pool() { static DevPool* p = new DevPool(); return *p; }
 // ------------------------------------------------------------------------------------------------
 // handle / workspace
 // ------------------------------------------------------------------------------------------------
-struct HostMirror {                 // pinned; filled by one async copy batch per call
+struct HostMirror {                 // one small device block + its pinned host twin, copied once per phase
   int binPtr[NBINS + 1];
   int err;
-  int pad;
+  int scratch2[2];                  // counts of the 513-2048 / 2049-4096 rows when a classification is unpacked
+  int qctr[8];                      // work-queue heads of the block-per-row kernels (zeroed with the rest per call)
   unsigned long long totalP;
   unsigned long long nnzC64;
 };
@@ -134,7 +137,7 @@ struct spgemm_handle {
   int* blockOff = nullptr;
   int* rowIds = nullptr;
   unsigned long long* tileSum = nullptr;
-  // small fixed device block: binPtr[NBINS+1] | err | pad | totalP | nnzC64   (same layout as HostMirror)
+  unsigned long long* blockP = nullptr;     // per-block sums of row flops (reduced by k_bin_scan)
   HostMirror* dsmall = nullptr;
   HostMirror* hsmall = nullptr;
   HostMirror mirror;                 // host copy taken at the end of the symbolic phase
@@ -142,14 +145,25 @@ struct spgemm_handle {
   int sym_m = -1;                    // rows of the pending symbolic phase, -1 = none
   hipEvent_t kev[2 * SPGEMM_NKERNELS];
   bool kused[SPGEMM_NKERNELS];
+  // side streams: the per-bin kernels of one phase are independent; SPGEMM_CONCURRENT=1 runs them concurrently
+  // (default off: the 155 KB-LDS big-row kernel owns the CUs it runs on, overlap measured slower than serial)
+  static constexpr int NSIDE = 4;
+  hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t fork_ev = nullptr;
+  hipEvent_t join_ev[NSIDE] = {nullptr, nullptr, nullptr, nullptr};
+  bool serial = true;
+  // column bitmaps of the big rows, saved by the symbolic pass for the rank kernel (n <= BIG_WC).  Sized from
+  // the previous calls (the number of big rows is only known on the host after the symbolic phase).
+  unsigned* bigBitmaps = nullptr;
+  int bm_cap = 0;
   spgemm_stats stats;
 };
 
 static int ws_free(spgemm_handle* h) {
   hipFree(h->rowFlops); hipFree(h->binId); hipFree(h->blockHist); hipFree(h->blockOff);
-  hipFree(h->rowIds); hipFree(h->tileSum);
+  hipFree(h->rowIds); hipFree(h->tileSum); hipFree(h->blockP);
   h->rowFlops = nullptr; h->binId = nullptr; h->blockHist = nullptr; h->blockOff = nullptr;
-  h->rowIds = nullptr; h->tileSum = nullptr; h->cap_m = -1;
+  h->rowIds = nullptr; h->tileSum = nullptr; h->blockP = nullptr; h->cap_m = -1;
   return SPGEMM_OK;
 }
 
@@ -165,6 +179,7 @@ static int ws_ensure(spgemm_handle* h, int m) {
   HIPCHK(hipMalloc((void**)&h->blockOff, sizeof(int) * nblk * NBINS));
   HIPCHK(hipMalloc((void**)&h->rowIds, sizeof(int) * cap));
   HIPCHK(hipMalloc((void**)&h->tileSum, sizeof(unsigned long long) * ntile));
+  HIPCHK(hipMalloc((void**)&h->blockP, sizeof(unsigned long long) * nblk));
   h->cap_m = (int)std::min<size_t>(cap, 0x7fffffff);
   return SPGEMM_OK;
 }
@@ -195,12 +210,20 @@ extern "C" int spgemm_hip_create(spgemm_handle** out, int device) {
   for (auto& e : h->ev) HIPCHK(hipEventCreate(&e));
   for (auto& e : h->kev) HIPCHK(hipEventCreate(&e));
   for (auto& u : h->kused) u = false;
+  { const char* e = getenv("SPGEMM_CONCURRENT"); h->serial = !(e && e[0] == '1'); }
+  for (auto& st : h->side) {
+    if (h->serial) st = h->stream;
+    else HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  }
+  HIPCHK(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+  for (auto& e : h->join_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(hipMalloc((void**)&h->dsmall, sizeof(HostMirror)));
   HIPCHK(hipHostMalloc((void**)&h->hsmall, sizeof(HostMirror), hipHostMallocDefault));
   memset(&h->stats, 0, sizeof(h->stats));
   // the big-row kernels use more than the default 64 KB of dynamic LDS
   HIPCHK(hipFuncSetAttribute((const void*)k_sym_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigSymShared)));
   HIPCHK(hipFuncSetAttribute((const void*)k_num_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigNumShared)));
+  HIPCHK(hipFuncSetAttribute((const void*)k_num_bighash, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigHashShared)));
   *out = h;
   return SPGEMM_OK;
 }
@@ -209,11 +232,15 @@ extern "C" int spgemm_hip_destroy(spgemm_handle* h) {
   if (!h) return SPGEMM_OK;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  for (auto& st : h->side) if (st && st != h->stream) { hipStreamSynchronize(st); hipStreamDestroy(st); }
   ws_free(h);
+  hipFree(h->bigBitmaps);
   hipFree(h->dsmall);
   hipHostFree(h->hsmall);
   for (auto& e : h->ev) if (e) hipEventDestroy(e);
   for (auto& e : h->kev) if (e) hipEventDestroy(e);
+  if (h->fork_ev) hipEventDestroy(h->fork_ev);
+  for (auto& e : h->join_ev) if (e) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return SPGEMM_OK;
@@ -264,16 +291,18 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 static inline int clampi(long long v, int lo, int hi) { return (int)std::max<long long>(lo, std::min<long long>(v, hi)); }
 
 static const char* kKernelNames[SPGEMM_NKERNELS] = {
-    "k_row_flops", "k_bin_scan", "k_scatter_rows", "k_sym_small<4,32>", "k_sym_small<8,128>", "k_sym_hash<1,1024>",
-    "k_sym_hash<8,8192>", "k_sym_big", "k_scan(3 launches)", "k_num_small<4,32>", "k_num_small<8,128>",
-    "k_num_hash<1,1024>", "k_num_hash<8,8192>", "k_num_big", "", ""};
+    "k_row_flops", "k_bin_scan", "k_scatter_rows", "k_sym_small<4,32>", "k_sym_g16", "k_sym_hash<1,1024>",
+    "k_sym_hash<4,4096>", "k_sym_hash<8,8192>", "k_sym_big", "k_scan(3 launches)", "k_num_small<4,32>", "k_num_g16",
+    "k_num_hash<1,1024>", "k_num_hash<4,4096>", "k_num_hash<8,8192>", "k_num_big", "k_num_bighash", "", "", ""};
 extern "C" const char* spgemm_hip_kernel_name(int id) { return (id >= 0 && id < SPGEMM_NKERNELS) ? kKernelNames[id] : ""; }
 
-// every launch is bracketed by two events on the handle's stream (per-kernel durations for bench.py's roofline)
+// every launch is bracketed by two events on its stream (per-kernel durations for bench.py's roofline)
 struct KTimer {
-  spgemm_handle* h; int id;
-  KTimer(spgemm_handle* h_, int id_) : h(h_), id(id_) { hipEventRecord(h->kev[2 * id], h->stream); h->kused[id] = true; }
-  ~KTimer() { hipEventRecord(h->kev[2 * id + 1], h->stream); }
+  spgemm_handle* h; int id; hipStream_t s;
+  KTimer(spgemm_handle* h_, int id_, hipStream_t s_ = nullptr) : h(h_), id(id_), s(s_ ? s_ : h_->stream) {
+    hipEventRecord(h->kev[2 * id], s); h->kused[id] = true;
+  }
+  ~KTimer() { hipEventRecord(h->kev[2 * id + 1], s); }
 };
 
 static void collect_kernel_times(spgemm_handle* h, bool reset) {
@@ -284,6 +313,21 @@ static void collect_kernel_times(spgemm_handle* h, bool reset) {
   }
 }
 
+// fork: the side streams wait for everything queued on the main stream so far
+static void fork_streams(spgemm_handle* h) {
+  if (h->serial) return;
+  hipEventRecord(h->fork_ev, h->stream);
+  for (auto& st : h->side) hipStreamWaitEvent(st, h->fork_ev, 0);
+}
+// join: the main stream waits for the side streams
+static void join_streams(spgemm_handle* h) {
+  if (h->serial) return;
+  for (int i = 0; i < spgemm_handle::NSIDE; ++i) {
+    hipEventRecord(h->join_ev[i], h->side[i]);
+    hipStreamWaitEvent(h->stream, h->join_ev[i], 0);
+  }
+}
+
 // flops + bins: K1, K2, K3.  Also presets IC[row] for rows with 0 / 1 products.
 static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, int m, int* dIC) {
   const int nblk = cdiv(m, K1_THREADS);
@@ -291,10 +335,10 @@ static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, con
   if (m > 0) {
     { KTimer t(h, SPGEMM_K_ROW_FLOPS);
       hipLaunchKernelGGL(k_row_flops, dim3(nblk), dim3(K1_THREADS), 0, h->stream, m, dIA, dJA, dIB, h->rowFlops,
-                         h->binId, h->blockHist, &h->dsmall->totalP, dIC); }
+                         h->binId, h->blockHist, h->blockP, dIC); }
     { KTimer t(h, SPGEMM_K_BIN_SCAN);
       hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, h->stream, nblk, h->blockHist, h->blockOff,
-                         h->dsmall->binPtr); }
+                         h->dsmall->binPtr, h->blockP, &h->dsmall->totalP); }
     { KTimer t(h, SPGEMM_K_SCATTER);
       hipLaunchKernelGGL(k_scatter_rows, dim3(nblk), dim3(K1_THREADS), 0, h->stream, m, h->binId, h->blockOff,
                          h->rowIds); }
@@ -303,29 +347,35 @@ static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, con
   return SPGEMM_OK;
 }
 
-// symbolic pass over bins 2..7 (bins 0/1 were preset by K1).  Bin sizes are not known on the host
-// here (no sync): grids are capped by the CU count and every block strides over its bin.
+// symbolic pass over bins 2..8 (bins 0/1 were preset by K1).  Bin sizes are not known on the host
+// here (no sync): grids are capped by the CU count and every block strides / dequeues over its bin.
 static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, const int* dJB,
                            int m, int n, const int* rowIds, int* dIC) {
   if (m <= 0) return SPGEMM_OK;
   const int* bp = h->dsmall->binPtr;
   int* err = &h->dsmall->err;
+  int* qc = h->dsmall->qctr;
   const int cu = h->numCU;
+  fork_streams(h);
+  { hipStream_t st = h->side[3]; KTimer t(h, SPGEMM_K_SYM_BIG, st);
+    hipLaunchKernelGGL(k_sym_big, dim3(clampi(m, 1, cu)), dim3(BIG_THREADS), sizeof(BigSymShared), st, bp, 8,
+                       rowIds, dIA, dJA, dIB, dJB, n, dIC, h->bigBitmaps, h->bm_cap, qc + 0); }
+  { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_SYM_HASH8, st);
+    hipLaunchKernelGGL((k_sym_hash<8, 8192, 2>), dim3(clampi(m, 1, cu * 3)), dim3(512), 0, st, bp, 7, rowIds, dIA,
+                       dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 1); }
+  { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_SYM_HASH4, st);
+    hipLaunchKernelGGL((k_sym_hash<4, 4096, 2>), dim3(clampi(m, 1, cu * 8)), dim3(256), 0, st, bp, 6, rowIds, dIA,
+                       dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 2); }
+  { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_SYM_HASH1, st);
+    hipLaunchKernelGGL((k_sym_hash<1, 1024, 2>), dim3(clampi(m, 1, cu * 32)), dim3(64), 0, st, bp, 5, rowIds, dIA,
+                       dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 3); }
+  { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_SYM_G16, st);
+    hipLaunchKernelGGL((k_sym_g16<128, 4>), dim3(clampi(cdiv(m, 16), 1, cu * 16)), dim3(256), 0, st, bp, 4,
+                       rowIds, dIA, dJA, dIB, dJB, h->rowFlops, dIC, err); }
   { KTimer t(h, SPGEMM_K_SYM_SMALL4);
     hipLaunchKernelGGL((k_sym_small<4, 32>), dim3(clampi(cdiv(m, 64), 1, cu * 8)), dim3(256), 0, h->stream, bp, 2, 4,
                        rowIds, dIA, dJA, dIB, dJB, h->rowFlops, dIC, err); }
-  { KTimer t(h, SPGEMM_K_SYM_SMALL8);
-    hipLaunchKernelGGL((k_sym_small<8, 128>), dim3(clampi(cdiv(m, 32), 1, cu * 8)), dim3(256), 0, h->stream, bp, 4, 5,
-                       rowIds, dIA, dJA, dIB, dJB, h->rowFlops, dIC, err); }
-  { KTimer t(h, SPGEMM_K_SYM_HASH1);
-    hipLaunchKernelGGL((k_sym_hash<1, 1024>), dim3(clampi(m, 1, cu * 24)), dim3(64), 0, h->stream, bp, 5, rowIds, dIA,
-                       dJA, dIB, dJB, h->rowFlops, dIC, err); }
-  { KTimer t(h, SPGEMM_K_SYM_HASH8);
-    hipLaunchKernelGGL((k_sym_hash<8, 8192>), dim3(clampi(m, 1, cu * 3)), dim3(512), 0, h->stream, bp, 6, rowIds, dIA,
-                       dJA, dIB, dJB, h->rowFlops, dIC, err); }
-  { KTimer t(h, SPGEMM_K_SYM_BIG);
-    hipLaunchKernelGGL(k_sym_big, dim3(clampi(m, 1, cu * 2)), dim3(BIG_THREADS), sizeof(BigSymShared), h->stream, bp, 7,
-                       rowIds, dIA, dJA, dIB, dJB, n, dIC); }
+  join_streams(h);
   HIPCHK(hipGetLastError());
   return SPGEMM_OK;
 }
@@ -346,23 +396,36 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const int* dJA, cons
                           const int* dIC, int* dJC, float* dC) {
   const int* bp = h->dsmall->binPtr;
   int* err = &h->dsmall->err;
+  int* qc = h->dsmall->qctr;
   const int cu = h->numCU;
   auto rows = [&](int lo, int hi) { return hostBinPtr[hi] - hostBinPtr[lo]; };
+  fork_streams(h);
+  if (rows(8, 9) > 0) {
+    hipStream_t st = h->side[3];
+    if (n <= BIG_WC) { KTimer t(h, SPGEMM_K_NUM_BIG, st);
+      hipLaunchKernelGGL(k_num_big, dim3(clampi(rows(8, 9), 1, cu)), dim3(BIG_THREADS), sizeof(BigNumShared), st,
+                         bp, 8, rowIds, dIA, dJA, dA, dIB, dJB, dB, n, dIC, dJC, dC, err, h->bigBitmaps, h->bm_cap,
+                         qc + 4);
+    } else { KTimer t(h, SPGEMM_K_NUM_BIGHASH, st);
+      hipLaunchKernelGGL(k_num_bighash, dim3(clampi(rows(8, 9), 1, cu)), dim3(BIG_THREADS), sizeof(BigHashShared), st,
+                         bp, 8, rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 4); }
+  }
+  if (rows(7, 8) > 0) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_NUM_HASH8, st);
+    hipLaunchKernelGGL((k_num_hash<8, 8192, 2>), dim3(clampi(rows(7, 8), 1, cu * 2)), dim3(512), 0, st, bp, 7,
+                       rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 5); }
+  if (rows(6, 7) > 0) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_NUM_HASH4, st);
+    hipLaunchKernelGGL((k_num_hash<4, 4096, 2>), dim3(clampi(rows(6, 7), 1, cu * 4)), dim3(256), 0, st, bp, 6,
+                       rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 6); }
+  if (rows(5, 6) > 0) { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_NUM_HASH1, st);
+    hipLaunchKernelGGL((k_num_hash<1, 1024, 2>), dim3(clampi(rows(5, 6), 1, cu * 16)), dim3(64), 0, st, bp, 5,
+                       rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 7); }
+  if (rows(4, 5) > 0) { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_NUM_G16, st);
+    hipLaunchKernelGGL((k_num_g16<128, 4>), dim3(clampi(cdiv(rows(4, 5), 16), 1, cu * 16)), dim3(256), 0, st,
+                       bp, 4, rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err); }
   if (rows(1, 4) > 0) { KTimer t(h, SPGEMM_K_NUM_SMALL4);
     hipLaunchKernelGGL((k_num_small<4, 32>), dim3(clampi(cdiv(rows(1, 4), 64), 1, cu * 8)), dim3(256), 0, h->stream, bp,
                        1, 4, rowIds, dIA, dJA, dA, dIB, dJB, dB, h->rowFlops, dIC, dJC, dC, err); }
-  if (rows(4, 5) > 0) { KTimer t(h, SPGEMM_K_NUM_SMALL8);
-    hipLaunchKernelGGL((k_num_small<8, 128>), dim3(clampi(cdiv(rows(4, 5), 32), 1, cu * 4)), dim3(256), 0, h->stream,
-                       bp, 4, 5, rowIds, dIA, dJA, dA, dIB, dJB, dB, h->rowFlops, dIC, dJC, dC, err); }
-  if (rows(5, 6) > 0) { KTimer t(h, SPGEMM_K_NUM_HASH1);
-    hipLaunchKernelGGL((k_num_hash<1, 1024>), dim3(clampi(rows(5, 6), 1, cu * 12)), dim3(64), 0, h->stream, bp, 5,
-                       rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err); }
-  if (rows(6, 7) > 0) { KTimer t(h, SPGEMM_K_NUM_HASH8);
-    hipLaunchKernelGGL((k_num_hash<8, 8192>), dim3(clampi(rows(6, 7), 1, cu * 2)), dim3(512), 0, h->stream, bp, 6,
-                       rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err); }
-  if (rows(7, 8) > 0) { KTimer t(h, SPGEMM_K_NUM_BIG);
-    hipLaunchKernelGGL(k_num_big, dim3(clampi(rows(7, 8), 1, cu)), dim3(BIG_THREADS), sizeof(BigNumShared), h->stream,
-                       bp, 7, rowIds, dIA, dJA, dA, dIB, dJB, dB, n, dIC, dJC, dC, err); }
+  join_streams(h);
   HIPCHK(hipGetLastError());
   return SPGEMM_OK;
 }
@@ -377,7 +440,7 @@ static int check_common(const void* a, const void* b, const void* c, int nnz, co
 // `pre` (optional) supplies a classification made earlier by hip_gpuFlopsClassify:
 // row ids grouped by bin + dflops + hv.
 struct PreClass { const int* drowIds; const int* hv; const int* dflops; };
-static int k_unpack_launch(spgemm_handle* h, int m, const PreClass& pre, int* dIC);
+static int unpack_classification(spgemm_handle* h, int m, const PreClass& pre, int* dIC);
 
 // phase 1: classify + symbolic + scan; one host sync at the end (nnzC, bin sizes, error flags)
 static int symbolic_phase(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, const int* dJB,
@@ -387,7 +450,7 @@ static int symbolic_phase(spgemm_handle* h, const int* dIA, const int* dJA, cons
   hipEventRecord(h->ev[0], s);
   h->cur_rowIds = h->rowIds;
   if (pre) {
-    CHK(k_unpack_launch(h, m, *pre, dIC));
+    CHK(unpack_classification(h, m, *pre, dIC));
     h->cur_rowIds = pre->drowIds;
   } else {
     CHK(launch_classify(h, dIA, dJA, dIB, m, dIC));
@@ -441,6 +504,15 @@ static int numeric_phase(spgemm_handle* h, const int* dIA, const int* dJA, const
   hipEventElapsedTime(&st.ms_numeric, h->ev[4], h->ev[5]);
   st.ms_total += st.ms_numeric;
   collect_kernel_times(h, false);
+  // room for the big rows' bitmaps next time (rank kernel only)
+  const int nbig = h->mirror.binPtr[NBINS] - h->mirror.binPtr[NBINS - 1];
+  if (n <= BIG_WC && nbig > h->bm_cap) {
+    hipFree(h->bigBitmaps);
+    h->bigBitmaps = nullptr;
+    const int cap = nbig + nbig / 4 + 16;
+    if (hipMalloc((void**)&h->bigBitmaps, (size_t)cap * BIG_WORDS * sizeof(unsigned)) == hipSuccess) h->bm_cap = cap;
+    else { h->bm_cap = 0; (void)hipGetLastError(); }
+  }
   return SPGEMM_OK;
 }
 
@@ -527,9 +599,9 @@ extern "C" int hip_csr_row_flops(spgemm_handle* h, const int* dIA, const int* dJ
 // ------------------------------------------------------------------------------------------------
 // classification API (reference-shaped outputs)
 // ------------------------------------------------------------------------------------------------
-static void hv_from_binptr(const int* binPtr, int m, int hv[SPGEMM_HV_LEN], int* hv_len) {
+static void hv_from_binptr(const int* binPtr, int hv[SPGEMM_HV_LEN], int* hv_len) {
   // reference bins (dqueueId): 1:{0} 2:{1} 3:{2..4} 4:{5..16} 5:{17..64} 6:{65..512} 7:{>512}; element 0 of the
-  // (m+1)-long bin array is a dummy with 0 flops (bin 1).
+  // (m+1)-long bin array is a dummy with 0 flops (bin 1).  Internal bins 6,7,8 together are reference bin 7.
   int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   cnt[1] = 1 + (binPtr[1] - binPtr[0]);
   cnt[2] = binPtr[2] - binPtr[1];
@@ -537,11 +609,10 @@ static void hv_from_binptr(const int* binPtr, int m, int hv[SPGEMM_HV_LEN], int*
   cnt[4] = binPtr[4] - binPtr[3];
   cnt[5] = binPtr[5] - binPtr[4];
   cnt[6] = binPtr[6] - binPtr[5];
-  cnt[7] = binPtr[8] - binPtr[6];
+  cnt[7] = binPtr[NBINS] - binPtr[6];
   hv[0] = 0;
   int maxbin = 1;
   for (int b = 0; b < 8; ++b) { hv[b + 1] = hv[b] + cnt[b]; if (cnt[b] > 0) maxbin = b; }
-  (void)m;
   *hv_len = maxbin + 2;
 }
 
@@ -575,41 +646,43 @@ extern "C" int hip_gpuFlopsClassify(spgemm_handle* h, const int* dIA, const int*
   if (hipMemcpyAsync(h->hsmall, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
       hipStreamSynchronize(s) != hipSuccess)
     return cleanup(fail(SPGEMM_ERR_HIP, "classify failed: %s", hipGetErrorString(hipGetLastError())));
-  hv_from_binptr(h->hsmall->binPtr, m, hv, hv_len);
+  hv_from_binptr(h->hsmall->binPtr, hv, hv_len);
   if (total_flops) *total_flops = (long long)h->hsmall->totalP;
   h->stats.total_flops = (long long)h->hsmall->totalP;
   for (int b = 0; b < NBINS; ++b) h->stats.bin_rows[b] = h->hsmall->binPtr[b + 1] - h->hsmall->binPtr[b];
+  collect_kernel_times(h, true);
   pool().release(tmpIC);
   *drowIds = ids;
   *dflops = fl;
   return SPGEMM_OK;
 }
 
-// rebuild the internal view (rowFlops by row, 8-bin binPtr, IC presets) from a caller-held classification
+// rebuild the internal view (rowFlops by row, 9-bin binPtr, IC presets) from a caller-held classification
 __global__ void k_unpack_classify(int m, const int* __restrict__ rowIds, const int* __restrict__ dflops,
-                                  int* __restrict__ rowFlops, int* __restrict__ IC, int lo6, int* __restrict__ n6) {
+                                  int* __restrict__ rowFlops, int* __restrict__ IC, int lo6, int* __restrict__ n67) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  int is6 = 0;
+  int is6 = 0, is7 = 0;
   if (q < m) {
     const int r = rowIds[q];
     // dflops is an int scan (like the reference's): differences stay exact modulo 2^32
     const unsigned f = (unsigned)dflops[q + 1] - (unsigned)dflops[q];
     rowFlops[r] = f > 0x7fffffffu ? 0x7fffffff : (int)f;
     if (f <= 1u) IC[r] = (int)f;
-    is6 = (q >= lo6 && f <= 4096u) ? 1 : 0;
+    is6 = (q >= lo6 && f <= 2048u) ? 1 : 0;
+    is7 = (q >= lo6 && f > 2048u && f <= 4096u) ? 1 : 0;
   }
-  const unsigned long long mk = __ballot(is6);
-  if (smf::lane_id() == 0 && mk) atomicAdd(n6, __popcll(mk));
+  const unsigned long long m6 = __ballot(is6), m7 = __ballot(is7);
+  if (smf::lane_id() == 0) { if (m6) atomicAdd(&n67[0], __popcll(m6)); if (m7) atomicAdd(&n67[1], __popcll(m7)); }
 }
 
-__global__ void k_binptr_from_hv(int* binPtr, int h2, int h3, int h4, int h5, int h6, int h7, int m, const int* n6) {
+__global__ void k_binptr_from_hv(int* binPtr, int h2, int h3, int h4, int h5, int h6, int h7, int m, const int* n67) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     binPtr[0] = 0; binPtr[1] = h2 - 1; binPtr[2] = h3 - 1; binPtr[3] = h4 - 1; binPtr[4] = h5 - 1;
-    binPtr[5] = h6 - 1; binPtr[6] = h7 - 1; binPtr[7] = h7 - 1 + *n6; binPtr[8] = m;
+    binPtr[5] = h6 - 1; binPtr[6] = h7 - 1; binPtr[7] = h7 - 1 + n67[0]; binPtr[8] = binPtr[7] + n67[1]; binPtr[9] = m;
   }
 }
 
-static int k_unpack_launch(spgemm_handle* h, int m, const PreClass& pre, int* dIC) {
+static int unpack_classification(spgemm_handle* h, int m, const PreClass& pre, int* dIC) {
   if (!pre.drowIds || !pre.hv || !pre.dflops) return fail(SPGEMM_ERR_ARG, "classification pointers are null");
   const int* hv = pre.hv;
   for (int b = 0; b < 8; ++b)
@@ -617,11 +690,11 @@ static int k_unpack_launch(spgemm_handle* h, int m, const PreClass& pre, int* dI
   if (hv[8] != m + 1 || hv[1] != 0 || hv[2] < 1) return fail(SPGEMM_ERR_ARG, "hv does not describe %d rows", m);
   HIPCHK(hipMemsetAsync(h->dsmall, 0, sizeof(HostMirror), h->stream));
   if (m > 0) {
-    int* n6 = &h->dsmall->pad;
+    int* n67 = h->dsmall->scratch2;
     hipLaunchKernelGGL(k_unpack_classify, dim3(cdiv(m, 256)), dim3(256), 0, h->stream, m, pre.drowIds, pre.dflops,
-                       h->rowFlops, dIC, hv[7] - 1, n6);
+                       h->rowFlops, dIC, hv[7] - 1, n67);
     hipLaunchKernelGGL(k_binptr_from_hv, dim3(1), dim3(64), 0, h->stream, h->dsmall->binPtr, hv[2], hv[3], hv[4], hv[5],
-                       hv[6], hv[7], m, n6);
+                       hv[6], hv[7], m, n67);
   }
   HIPCHK(hipGetLastError());
   return SPGEMM_OK;

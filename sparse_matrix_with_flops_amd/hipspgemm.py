@@ -21,9 +21,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgemm_hip.so")
 
-NBINS = 8
+NBINS = 9
 HV_LEN = 9
-NKERNELS = 16
+NKERNELS = 20
 _I = C.POINTER(C.c_int)
 _F = C.POINTER(C.c_float)
 

@@ -90,16 +90,21 @@ def test_headline_config_device_resident(handle):
     g = META["synth"]["262144_42_2"]
     A = synth_csr(262144, 42, 2)
     dA = to_hs(A).toGpuCSR()
-    dC = hs.gpuSpMMWrapper(dA, dA, handle)
+    dC0 = hs.gpuSpMMWrapper(dA, dA, handle)      # first call: big-row bitmaps are rebuilt in the numeric pass
+    first = dC0.toCpuCSR()
+    dC0.deviceDispose()
+    dC = hs.gpuSpMMWrapper(dA, dA, handle)       # second call on the handle: bitmaps saved by the symbolic pass
     st = handle.stats()
     assert st["total_flops"] == g["P"] and st["nnzC"] == g["nnz"] and sum(st["bin_rows"]) == 262144
     raw = dC.toCpuCSR()
+    assert np.array_equal(first.rowPtr, raw.rowPtr)
     hs.sort_rows_device(dC, handle)
     srt = dC.toCpuCSR()
     dC.deviceDispose()
     dA.deviceDispose()
     want = po.omp_spmm(A, A)
     assert_parity(raw, want, what="headline raw")
+    assert_parity(first, want, what="headline first call")
     # device-side makeOrdered: columns ascending inside every row, same multiset
     cs, vs = canonical_arrays(raw.rowPtr, raw.colInd, raw.values)
     assert np.array_equal(srt.colInd, cs) and np.array_equal(srt.values, vs)
