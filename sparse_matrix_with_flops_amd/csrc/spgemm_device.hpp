@@ -110,26 +110,63 @@ __device__ __forceinline__ int log2_pow2(int p) { return 31 - __clz(p); }
 
 // ------------------------------------------------------------------------------------------------
 // LDS open-addressing hash (keys >= 0, EMPTY_KEY = -1), multiplicative hash, linear probing.
-// Returns the slot of `c`; *is_new is set when this call claimed the slot.  `size` is a power of
-// two >= 1.5 * (number of distinct keys), so a probe sequence always terminates; a bounded loop and an
-// error flag guard against corrupt inputs instead of hanging the GPU.
+// hash_insert: one key per lane (small-row kernels).  Returns the slot of `c`; *is_new is set when this call
+// claimed the slot.  `size` is a power of two >= 2 * (number of distinct keys), so a probe sequence always
+// terminates; a bounded loop and an error flag guard against corrupt inputs instead of hanging the GPU.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int hash_insert(int* keys, int size, int shift, int c, bool* is_new, int* err) {
   unsigned h = ((unsigned)c * 2654435761u) >> shift;
   const unsigned mask = (unsigned)size - 1u;
   *is_new = false;
   for (int probe = 0; probe < size; ++probe) {
-    int cur = lds_load(&keys[h]);
-    if (cur == c) return (int)h;
-    if (cur == EMPTY_KEY) {
-      int old = atomicCAS(&keys[h], EMPTY_KEY, c);
-      if (old == EMPTY_KEY) { *is_new = true; return (int)h; }
-      if (old == c) return (int)h;
-    }
+    const int old = atomicCAS(&keys[h], EMPTY_KEY, c);
+    if (old == EMPTY_KEY) { *is_new = true; return (int)h; }
+    if (old == c) return (int)h;
     h = (h + 1u) & mask;
   }
   atomicOr(err, ERRF_TABLE_FULL);
   return 0;
+}
+
+// U keys per lane at once, straight-line code: predication is done through the ADDRESS (a lane with nothing to
+// insert aims its CAS / add at a private dummy word), never through a branch, so the U LDS atomics of a probe
+// step issue back to back and their latencies overlap; hipcc otherwise wraps every conditional atomic in its
+// own exec-mask branch with an s_waitcnt right behind it.  CAS first: most products of a SpGEMM row touch their
+// column for the first time, so the claim usually succeeds in one LDS round trip.
+// vals == nullptr: symbolic (count only).  `dummy` = one private int per lane.  Returns the slots this lane claimed.
+template <int U>
+__device__ __forceinline__ int hash_insert_multi(int* keys, float* vals, int size, int shift, const bool (&act)[U],
+                                                 const int (&col)[U], const float (&val)[U], int* dummy, int* err) {
+  const unsigned mask = (unsigned)size - 1u;
+  unsigned h[U];
+  bool pend[U];
+  int claimed = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) { h[u] = ((unsigned)col[u] * 2654435761u) >> shift; pend[u] = act[u]; }
+  bool done = false;
+  for (int probe = 0; probe < size && !done; ++probe) {
+    int old[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) old[u] = atomicCAS(pend[u] ? &keys[h[u]] : dummy, EMPTY_KEY, col[u]);
+    bool more = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool fresh = pend[u] && old[u] == EMPTY_KEY;
+      const bool fin = fresh || old[u] == col[u];
+      claimed += fresh ? 1 : 0;
+      h[u] = (pend[u] && !fin) ? ((h[u] + 1u) & mask) : h[u];
+      pend[u] = pend[u] && !fin;
+      more = more || pend[u];
+    }
+    done = !__any(more);
+  }
+  if (!done) atomicOr(err, ERRF_TABLE_FULL);
+  if (vals) {
+    float* fdummy = reinterpret_cast<float*>(dummy);
+#pragma unroll
+    for (int u = 0; u < U; ++u) atomicAdd(act[u] ? &vals[h[u]] : fdummy, act[u] ? val[u] : 0.f);
+  }
+  return claimed;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -364,6 +401,23 @@ __global__ __launch_bounds__(256) void k_num_small(const int* __restrict__ binPt
   }
 }
 
+// ---- diagnostic build only (-DSMF_STAMPS): per-phase cycle sums, written by wave 0 lane 0 of every block into
+// a debug buffer that nothing else reads (guide §7 "In-kernel stamps").  Never compiled into the product.
+#ifdef SMF_STAMPS
+__device__ unsigned long long g_stamps[4][16];
+#define STAMP_DECL unsigned long long st_t0 = __builtin_readcyclecounter(), st_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}
+#define STAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_t0; st_t0 = t_; } while (0)
+#define STAMP_FLUSH(k) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_stamps[k][i_], st_acc[i_]); } while (0)
+#define STAMP_PARAMS , unsigned long long& st_t0, unsigned long long* st_acc
+#define STAMP_ARGS , st_t0, st_acc
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH(k)
+#define STAMP_PARAMS
+#define STAMP_ARGS
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Rows with 17..64 products: 16 lanes per row (4 rows per wave), products flattened over the 16 lanes.
 // The old "A entries one after the other" walk costs three dependent memory round trips per A entry;
@@ -528,7 +582,7 @@ __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr,
 // rounds of 64 consecutive products, U rounds per trip so that U gathers of B are in flight per wave.
 // A lane finds the A entry that owns its product with a branch-free binary search over the scan in LDS
 // (log2(64*NW) dependent ds_reads, the U searches of a trip interleave): no ballots, no fences, no
-// divergence in the walk.  f(active, col, val) is called in wave-uniform control flow (val = a*b).
+// divergence in the walk.  f(act[U], col[U], val[U]) is called in wave-uniform control flow (val = a*b).
 // ------------------------------------------------------------------------------------------------
 template <int NW, int U>
 struct RowStage {
@@ -536,13 +590,17 @@ struct RowStage {
   int off[WAVE * NW];      // IB[j] - exclusive scan: product p of the chunk lives at JB[off + p]
   float aval[WAVE * NW];
   int wsum[NW];
+  int dummy[WAVE * NW];    // one private word per lane: target of predicated-off atomics
 };
+
+// first chunk of A entries fetched ahead of time (wave-per-row kernels prefetch the next row's while they work)
+struct PreA { int j; float a; bool valid; };
 
 template <int NW, int U, bool NEED_VAL, class F>
 __device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, int ae,
                                                  const int* __restrict__ JA, const float* __restrict__ VA,
                                                  const int* __restrict__ IB, const int* __restrict__ JB,
-                                                 const float* __restrict__ VB, F&& f) {
+                                                 const float* __restrict__ VB, F&& f, PreA pre STAMP_PARAMS) {
   constexpr int K = WAVE * NW;
   const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
   for (int chunk = as; chunk < ae; chunk += K) {
@@ -551,10 +609,11 @@ __device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, in
     int len = 0, bs = 0;
     float a = 0.f;
     if (ap < ae) {
-      const int j = JA[ap];
+      const bool usePre = pre.valid && chunk == as;
+      const int j = usePre ? pre.j : JA[ap];
       bs = IB[j];
       len = IB[j + 1] - bs;
-      if (NEED_VAL) a = VA[ap];
+      if (NEED_VAL) a = usePre ? pre.a : VA[ap];
     }
     int incl = wave_incl_add(len);
     if (NW > 1) {
@@ -568,16 +627,32 @@ __device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, in
     st.off[tid] = bs - (incl - len);
     if (NEED_VAL) st.aval[tid] = a;
     __syncthreads();
+    STAMP(8);
     const int T = st.incl[K - 1];
     const int nrounds = (T + WAVE - 1) / WAVE;
+    // boundaries between the 64-entry groups, wave-uniform, kept in registers: the top log2(NW) levels of the
+    // search are VALU compares against them instead of dependent LDS reads
+    int bnd[NW > 1 ? NW - 1 : 1];
+    if (NW > 1) {
+#pragma unroll
+      for (int i = 0; i < NW - 1; ++i) bnd[i] = __builtin_amdgcn_readfirstlane(st.incl[i * WAVE + WAVE - 1]);
+    }
     // ---- rounds: wave w owns rounds w, w+NW, ...; U of them per trip
     for (int r0 = w; r0 < nrounds; r0 += NW * U) {
       int p[U], e[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) { p[u] = (r0 + u * NW) * WAVE + lane; e[u] = 0; }
-      // first entry with incl > p, all U searches in lock step
+      for (int u = 0; u < U; ++u) {
+        p[u] = (r0 + u * NW) * WAVE + lane;
+        int grp = 0;
+        if (NW > 1) {
 #pragma unroll
-      for (int sft = K / 2; sft >= 1; sft >>= 1) {
+          for (int i = 0; i < NW - 1; ++i) grp += bnd[i] <= p[u] ? 1 : 0;
+        }
+        e[u] = grp * WAVE;
+      }
+      // first entry with incl > p inside the group, all U searches in lock step
+#pragma unroll
+      for (int sft = WAVE / 2; sft >= 1; sft >>= 1) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int c = e[u] + sft;
@@ -587,34 +662,75 @@ __device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, in
       int col[U];
       float val[U];
       bool act[U];
+#ifdef SMF_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      STAMP(5);                                   // search done
+#endif
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < U; ++u) {                // straight-line: lanes past the end re-read product 0
         act[u] = p[u] < T;
-        col[u] = 0;
-        val[u] = 0.f;
-        if (act[u]) {
-          const int jb = st.off[e[u]] + p[u];
-          col[u] = JB[jb];
-          if (NEED_VAL) val[u] = st.aval[e[u]] * VB[jb];
-        }
+        const int ee = act[u] ? e[u] : 0;
+        const int jb = st.off[ee] + (act[u] ? p[u] : 0);
+        col[u] = JB[jb];
+        val[u] = NEED_VAL ? st.aval[ee] * VB[jb] : 0.f;
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u) f(act[u], col[u], val[u]);
+#ifdef SMF_STAMPS
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      STAMP(6);                                   // gather landed
+#endif
+      f(act, col, val);
+#ifdef SMF_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      STAMP(9);                                   // insert done
+#endif
     }
+    STAMP(7);
     __syncthreads();
+    STAMP(10);
   }
 }
+
+// call sites without a prefetched chunk
+template <int NW, int U, bool NEED_VAL, class F>
+__device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, int ae, const int* __restrict__ JA,
+                                                 const float* __restrict__ VA, const int* __restrict__ IB,
+                                                 const int* __restrict__ JB, const float* __restrict__ VB, F&& f STAMP_PARAMS) {
+  for_each_product<NW, U, NEED_VAL>(st, as, ae, JA, VA, IB, JB, VB, f, PreA{0, 0.f, false} STAMP_ARGS);
+}
+
+#ifdef SMF_STAMPS
+// un-instrumented call sites of the diagnostic build
+template <int NW, int U, bool NEED_VAL, class F>
+__device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, int ae, const int* __restrict__ JA,
+                                                 const float* __restrict__ VA, const int* __restrict__ IB,
+                                                 const int* __restrict__ JB, const float* __restrict__ VB, F&& f) {
+  unsigned long long t0 = 0, acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+  for_each_product<NW, U, NEED_VAL>(st, as, ae, JA, VA, IB, JB, VB, f, PreA{0, 0.f, false}, t0, acc);
+}
+template <int NW, int U, bool NEED_VAL, class F>
+__device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, int ae, const int* __restrict__ JA,
+                                                 const float* __restrict__ VA, const int* __restrict__ IB,
+                                                 const int* __restrict__ JB, const float* __restrict__ VB, F&& f, PreA pre) {
+  unsigned long long t0 = 0, acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+  for_each_product<NW, U, NEED_VAL>(st, as, ae, JA, VA, IB, JB, VB, f, pre, t0, acc);
+}
+#endif
 
 // dynamic row scheduling for block-per-row kernels: rows of a bin differ by up to 8x in work, a static
 // round-robin leaves the CUs with the light rows idle.  One agent-scope atomic per row (guide: "dequeue",
 // ~0.3-1 us, overlapped with the previous row's tail by fetching one row ahead).
-__device__ __forceinline__ int next_row(int* ctr, int* slot) {
-  if (threadIdx.x == 0) *slot = atomicAdd(ctr, 1);
+// A single queue word saturates near 88 dequeues/us (guide, "dequeue"): kernels whose rows are short take R
+// rows per atomic.
+template <int R>
+__device__ __forceinline__ int next_row(int* ctr, int* slot, int prev) {
+  if (R > 1 && prev >= 0 && (prev + 1) % R != 0) return prev + 1;      // still inside the batch (block-uniform)
+  if (threadIdx.x == 0) *slot = atomicAdd(ctr, R);
   __syncthreads();
   const int q = *slot;
   __syncthreads();
   return q;
 }
+__device__ __forceinline__ int next_row(int* ctr, int* slot) { return next_row<1>(ctr, slot, -1); }
 
 // per-row metadata, fetched one row ahead of use so that the dependent rowIds -> IA/IC loads of the
 // next row overlap the current row's work
@@ -629,6 +745,14 @@ __device__ __forceinline__ RowMeta load_meta_num(const int* rows, int q, int cou
   RowMeta mtd{0, 0, 0, 0, 0};
   if (q < count) { mtd.row = rows[q]; mtd.as = IA[mtd.row]; mtd.ae = IA[mtd.row + 1]; mtd.x0 = IC[mtd.row]; mtd.x1 = IC[mtd.row + 1]; }
   return mtd;
+}
+
+// wave-per-row kernels: this lane's A entry of the row's first chunk, fetched one row ahead
+__device__ __forceinline__ PreA load_pre(const RowMeta& mtd, const int* JA, const float* VA, bool needVal) {
+  PreA p{0, 0.f, true};
+  const int ap = mtd.as + lane_id();
+  if (ap < mtd.ae) { p.j = JA[ap]; if (needVal) p.a = VA[ap]; }
+  return p;
 }
 
 // block-wide exclusive scan of one int per thread (NW waves); returns exclusive value, *total = sum
@@ -658,31 +782,42 @@ __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ 
                                                          const int* __restrict__ IB, const int* __restrict__ JB,
                                                          const int* __restrict__ rowFlops, int* __restrict__ IC,
                                                          int* __restrict__ err, int* __restrict__ qctr) {
-  __shared__ int keys[TBL];
+  __shared__ __attribute__((aligned(16))) int keys[TBL];
   __shared__ RowStage<NW, U> st;
   __shared__ int cnt_s;
   __shared__ int qslot;
   const int tid = threadIdx.x, lane = lane_id();
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
   const int* rows = rowIds + first;
-  int q = NW > 1 ? next_row(qctr, &qslot) : (int)blockIdx.x;
+  constexpr int QB = NW >= 8 ? 2 : 4;            // rows per dequeue
+  const int stride = (int)gridDim.x;
+  int q = NW > 1 ? next_row<QB>(qctr, &qslot, -1) : (int)blockIdx.x;
   RowMeta cur = load_meta_sym(rows, q, count, IA, rowFlops);
+  // NW == 1: two rows of metadata and one row of A entries are in flight ahead of the row being processed
+  RowMeta nxt = NW == 1 ? load_meta_sym(rows, q + stride, count, IA, rowFlops) : RowMeta{0, 0, 0, 0, 0};
+  PreA pc = NW == 1 ? load_pre(cur, JA, nullptr, false) : PreA{0, 0.f, false};
   while (q < count) {
-    const int qn = NW > 1 ? next_row(qctr, &qslot) : q + (int)gridDim.x;
-    const RowMeta nxt = load_meta_sym(rows, qn, count, IA, rowFlops);
+    int qn;
+    PreA pn{0, 0.f, false};
+    RowMeta nn{0, 0, 0, 0, 0};
+    if (NW == 1) {
+      qn = q + stride;
+      nn = load_meta_sym(rows, qn + stride, count, IA, rowFlops);
+      pn = load_pre(nxt, JA, nullptr, false);
+    } else {
+      qn = next_row<QB>(qctr, &qslot, q);
+      nxt = load_meta_sym(rows, qn, count, IA, rowFlops);
+    }
     const int size = next_pow2_clamped(2 * cur.x0, 64, TBL);
     const int shift = 32 - log2_pow2(size);
     for (int i = tid; i < size; i += WAVE * NW) keys[i] = EMPTY_KEY;
     if (tid == 0) cnt_s = 0;
     __syncthreads();
     int mine = 0;
-    for_each_product<NW, U, false>(st, cur.as, cur.ae, JA, nullptr, IB, JB, nullptr, [&](bool active, int col, float) {
-      if (active) {
-        bool isnew;
-        hash_insert(keys, size, shift, col, &isnew, err);
-        mine += isnew ? 1 : 0;
-      }
-    });
+    for_each_product<NW, U, false>(st, cur.as, cur.ae, JA, nullptr, IB, JB, nullptr,
+                                   [&](const bool (&act)[U], const int (&col)[U], const float (&val)[U]) {
+      mine += hash_insert_multi<U>(keys, nullptr, size, shift, act, col, val, &st.dummy[threadIdx.x], err);
+    }, pc);
     const int ws = wave_sum(mine);
     if (NW == 1) {
       if (lane == 0) IC[cur.row] = ws;
@@ -693,6 +828,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ 
     }
     __syncthreads();
     cur = nxt;
+    if (NW == 1) { nxt = nn; pc = pn; }
     q = qn;
   }
 }
@@ -707,7 +843,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
                                                          const int* __restrict__ IC, int* __restrict__ JC,
                                                          float* __restrict__ C, int* __restrict__ err,
                                                          int* __restrict__ qctr) {
-  __shared__ int keys[TBL];
+  __shared__ __attribute__((aligned(16))) int keys[TBL];
   __shared__ float vals[TBL];
   __shared__ RowStage<NW, U> st;
   __shared__ int red[NW];
@@ -716,34 +852,52 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
   constexpr int T = WAVE * NW;
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
   const int* rows = rowIds + first;
-  int q = NW > 1 ? next_row(qctr, &qslot) : (int)blockIdx.x;
+  constexpr int QB = NW >= 8 ? 2 : 4;            // rows per dequeue
+  const int stride = (int)gridDim.x;
+  int q = NW > 1 ? next_row<QB>(qctr, &qslot, -1) : (int)blockIdx.x;
   RowMeta cur = load_meta_num(rows, q, count, IA, IC);
+  RowMeta nxt = NW == 1 ? load_meta_num(rows, q + stride, count, IA, IC) : RowMeta{0, 0, 0, 0, 0};
+  PreA pc = NW == 1 ? load_pre(cur, JA, VA, true) : PreA{0, 0.f, false};
+  STAMP_DECL;
   while (q < count) {
-    const int qn = NW > 1 ? next_row(qctr, &qslot) : q + (int)gridDim.x;
-    const RowMeta nxt = load_meta_num(rows, qn, count, IA, IC);
+    STAMP(0);
+    int qn;
+    PreA pn{0, 0.f, false};
+    RowMeta nn{0, 0, 0, 0, 0};
+    if (NW == 1) {
+      qn = q + stride;
+      nn = load_meta_num(rows, qn + stride, count, IA, IC);
+      pn = load_pre(nxt, JA, VA, true);
+    } else {
+      qn = next_row<QB>(qctr, &qslot, q);
+      nxt = load_meta_num(rows, qn, count, IA, IC);
+    }
+    STAMP(1);
     const int off = cur.x0;
     const int want = cur.x1 - off;                      // exact distinct count from the symbolic pass
     const int size = next_pow2_clamped(2 * want, T > 64 ? T : 64, TBL);
     const int shift = 32 - log2_pow2(size);
     for (int i = tid; i < size; i += T) { keys[i] = EMPTY_KEY; vals[i] = 0.f; }
     __syncthreads();
-    for_each_product<NW, U, true>(st, cur.as, cur.ae, JA, VA, IB, JB, VB, [&](bool active, int col, float v) {
-      if (active) {
-        bool isnew;
-        const int s = hash_insert(keys, size, shift, col, &isnew, err);
-        atomicAdd(&vals[s], v);
-      }
-    });
+    STAMP(2);
+    for_each_product<NW, U, true>(st, cur.as, cur.ae, JA, VA, IB, JB, VB,
+                                  [&](const bool (&act)[U], const int (&col)[U], const float (&val)[U]) {
+      hash_insert_multi<U>(keys, vals, size, shift, act, col, val, &st.dummy[threadIdx.x], err);
+    }, pc STAMP_ARGS);
+    STAMP(3);
     // compaction: wave w sweeps the contiguous slots [w*per, w*per+per) 64 at a time, so that a wave's stores
-    // land on consecutive output positions
+    // land on consecutive output positions.  One wave: a single pass; several waves: count, scan, write.
     const int per = size / NW;
     const int lane = lane_id(), w = tid >> 6;
-    int mine = 0;
-    for (int i = lane; i < per; i += WAVE) mine += keys[w * per + i] != EMPTY_KEY;
-    int wtot = wave_sum(mine);
     int total;
-    int pos = off + block_excl_scan<NW>(lane == 0 ? wtot : 0, red, &total);
-    pos = __builtin_amdgcn_readfirstlane(pos);
+    int pos = off;
+    if (NW > 1) {
+      int mine = 0;
+      for (int i = lane; i < per; i += WAVE) mine += keys[w * per + i] != EMPTY_KEY;
+      const int wtot = wave_sum(mine);
+      pos = off + block_excl_scan<NW>(lane == 0 ? wtot : 0, red, &total);
+      pos = __builtin_amdgcn_readfirstlane(pos);
+    }
     for (int i0 = 0; i0 < per; i0 += WAVE) {
       const int sl = w * per + i0 + lane;
       const int kx = keys[sl];
@@ -752,11 +906,15 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
       if (occ) { const int o = pos + mask_rank(mk); JC[o] = kx; C[o] = vals[sl]; }
       pos += __popcll(mk);
     }
+    if (NW == 1) total = pos - off;
     if (tid == 0 && total != want) atomicOr(err, ERRF_COUNT_MISMATCH);
     __syncthreads();
+    STAMP(4);
     cur = nxt;
+    if (NW == 1) { nxt = nn; pc = pn; }
     q = qn;
   }
+  STAMP_FLUSH(NW == 1 ? 1 : NW == 4 ? 2 : 3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -785,12 +943,17 @@ struct BigSymShared {
   RowStage<BIG_NW, BIG_U> st;
   int red[BIG_NW];
 };
+constexpr int BIG_GROUPS = BIG_WORDS / WAVE;   // 128 groups of 64 bitmap words
+constexpr int BIG_GPW = BIG_GROUPS / BIG_NW;   // 8 groups per wave, interleaved (dense column ranges spread over all waves)
 struct BigNumShared {
   unsigned bitmap[BIG_WORDS];
   int prefix[BIG_WORDS];
   float acc[BIG_CAP];
   RowStage<BIG_NW, BIG_U> st;
   int red[BIG_NW];
+  int gtot[BIG_GROUPS];
+  int gbase[BIG_GROUPS];
+  int cnt;
 };
 struct BigHashShared {
   int keys[BH_SLOTS];
@@ -831,10 +994,13 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sym_big(const int* __restrict__
       const int words = (wc + 31) >> 5;
       for (int i = tid; i < words; i += BIG_THREADS) sh.bitmap[i] = 0u;
       __syncthreads();
-      for_each_product<BIG_NW, BIG_U, false>(sh.st, as, ae, JA, nullptr, IB, JB, nullptr, [&](bool active, int col, float) {
-        if (active) {
-          const int c = col - w0;
-          if ((unsigned)c < (unsigned)wc) atomicOr(&sh.bitmap[c >> 5], 1u << (c & 31));
+      for_each_product<BIG_NW, BIG_U, false>(sh.st, as, ae, JA, nullptr, IB, JB, nullptr,
+                                             [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&)[BIG_U]) {
+#pragma unroll
+        for (int u = 0; u < BIG_U; ++u) {            // predicated by value: OR-ing 0 changes nothing
+          const int c = col[u] - w0;
+          const bool ok = act[u] && (unsigned)c < (unsigned)wc;
+          atomicOr(&sh.bitmap[ok ? c >> 5 : 0], ok ? 1u << (c & 31) : 0u);
         }
       });
       int mine = 0;
@@ -865,7 +1031,9 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
   BigNumShared& sh = *reinterpret_cast<BigNumShared*>(smem_raw);
   const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
+  STAMP_DECL;
   for (int q = next_row(qctr, &sh.red[0]); q < count; q = next_row(qctr, &sh.red[0])) {
+    STAMP(0);
     const int row = rowIds[first + q];
     const int as = IA[row], ae = IA[row + 1];
     const int outBase = IC[row];
@@ -878,36 +1046,57 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
     } else {
       for (int i = tid; i < BIG_WORDS; i += BIG_THREADS) sh.bitmap[i] = 0u;
       __syncthreads();
-      for_each_product<BIG_NW, BIG_U, false>(sh.st, as, ae, JA, nullptr, IB, JB, nullptr, [&](bool active, int col, float) {
-        if (active && (unsigned)col < (unsigned)n) atomicOr(&sh.bitmap[col >> 5], 1u << (col & 31));
+      for_each_product<BIG_NW, BIG_U, false>(sh.st, as, ae, JA, nullptr, IB, JB, nullptr,
+                                             [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&)[BIG_U]) {
+#pragma unroll
+        for (int u = 0; u < BIG_U; ++u) {
+          const bool ok = act[u] && (unsigned)col[u] < (unsigned)n;
+          atomicOr(&sh.bitmap[ok ? col[u] >> 5 : 0], ok ? 1u << (col[u] & 31) : 0u);
+        }
       });
     }
-    // exclusive popcount prefix over the words: thread t owns words [t*WPT, t*WPT+WPT)
-    int loc[BIG_WPT];
-    int mine = 0;
+    STAMP(1);
+    // exclusive popcount prefix over the words.  Wave w owns the 64-word groups w, w+16, ...: consecutive lanes
+    // read consecutive words (no bank conflicts) and a dense column range is shared by all waves.
+    int lexcl[BIG_GPW];
 #pragma unroll
-    for (int i = 0; i < BIG_WPT; ++i) { loc[i] = mine; mine += __popc(sh.bitmap[tid * BIG_WPT + i]); }
-    const int incl = wave_incl_add(mine);
+    for (int si = 0; si < BIG_GPW; ++si) {
+      const int g = w + si * BIG_NW;
+      const int pc = __popc(sh.bitmap[g * WAVE + lane]);
+      const int incl = wave_incl_add(pc);
+      lexcl[si] = incl - pc;
+      if (lane == 63) sh.gtot[g] = incl;
+    }
     __syncthreads();
-    if (lane == 63) sh.red[w] = incl;
+    if (w == 0) {
+      const int s0 = sh.gtot[2 * lane], s1 = sh.gtot[2 * lane + 1];
+      const int incl = wave_incl_add(s0 + s1);
+      sh.gbase[2 * lane] = incl - s0 - s1;
+      sh.gbase[2 * lane + 1] = incl - s1;
+      if (lane == 63) sh.cnt = incl;
+    }
     __syncthreads();
-    int woff = 0, cntw = 0;
-    for (int i = 0; i < BIG_NW; ++i) { const int s = sh.red[i]; cntw += s; if (i < w) woff += s; }
-    const int texcl = woff + incl - mine;
+    int cntw = sh.cnt;
 #pragma unroll
-    for (int i = 0; i < BIG_WPT; ++i) sh.prefix[tid * BIG_WPT + i] = texcl + loc[i];
+    for (int si = 0; si < BIG_GPW; ++si) {
+      const int g = w + si * BIG_NW;
+      lexcl[si] += sh.gbase[g];
+      sh.prefix[g * WAVE + lane] = lexcl[si];
+    }
     __syncthreads();
     if (outBase + cntw != outEnd) { if (tid == 0) atomicOr(err, ERRF_COUNT_MISMATCH); cntw = min(cntw, max(0, outEnd - outBase)); }
     // BIG_CAP ranks at a time: column indices first (already sorted; scattered into LDS by rank, then stored
     // coalesced), then the values accumulated by rank
     int* accI = reinterpret_cast<int*>(sh.acc);
+    STAMP(2);
     for (int lo = 0; lo < cntw; lo += BIG_CAP) {
       const int span = min(BIG_CAP, cntw - lo);
 #pragma unroll
-      for (int i = 0; i < BIG_WPT; ++i) {
-        unsigned bits = sh.bitmap[tid * BIG_WPT + i];
-        int pos = texcl + loc[i] - lo;
-        const int cbase = (tid * BIG_WPT + i) * 32;
+      for (int si = 0; si < BIG_GPW; ++si) {
+        const int wd = (w + si * BIG_NW) * WAVE + lane;
+        unsigned bits = sh.bitmap[wd];
+        int pos = lexcl[si] - lo;
+        const int cbase = wd * 32;
         while (bits) {
           const int b = __ffs(bits) - 1;
           bits &= bits - 1;
@@ -915,23 +1104,39 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
           ++pos;
         }
       }
+      STAMP(11);
       __syncthreads();
+      STAMP(7);
       for (int i = tid; i < span; i += BIG_THREADS) JC[outBase + lo + i] = accI[i];
       __syncthreads();
+      STAMP(3);
       for (int i = tid; i < span; i += BIG_THREADS) sh.acc[i] = 0.f;
       __syncthreads();
-      for_each_product<BIG_NW, BIG_U, true>(sh.st, as, ae, JA, VA, IB, JB, VB, [&](bool active, int col, float v) {
-        if (active && (unsigned)col < (unsigned)n) {
-          const int wi = col >> 5;
-          const int rk = sh.prefix[wi] + __popc(sh.bitmap[wi] & ((1u << (col & 31)) - 1u)) - lo;
-          if ((unsigned)rk < (unsigned)span) atomicAdd(&sh.acc[rk], v);
+      STAMP(4);
+      for_each_product<BIG_NW, BIG_U, true>(sh.st, as, ae, JA, VA, IB, JB, VB,
+                                            [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&val)[BIG_U]) {
+        int rk[BIG_U];
+#pragma unroll
+        for (int u = 0; u < BIG_U; ++u) {          // the U rank lookups (two LDS reads each) overlap
+          const int c = act[u] && (unsigned)col[u] < (unsigned)n ? col[u] : 0;
+          const int wi = c >> 5;
+          rk[u] = sh.prefix[wi] + __popc(sh.bitmap[wi] & ((1u << (c & 31)) - 1u)) - lo;
         }
-      });
+#pragma unroll
+        for (int u = 0; u < BIG_U; ++u) {          // predicated by value: adding 0 to this lane's own dummy word
+          const bool ok = act[u] && (unsigned)col[u] < (unsigned)n && (unsigned)rk[u] < (unsigned)span;
+          atomicAdd(ok ? &sh.acc[rk[u]] : reinterpret_cast<float*>(&sh.st.dummy[threadIdx.x]), ok ? val[u] : 0.f);
+        }
+      } STAMP_ARGS);
+      STAMP(5);
       for (int i = tid; i < span; i += BIG_THREADS) C[outBase + lo + i] = sh.acc[i];
       __syncthreads();
+      STAMP(6);
     }
     __syncthreads();
   }
+  STAMP(7);
+  STAMP_FLUSH(0);
 }
 
 // numeric B (any n): multi-pass LDS hash
@@ -961,16 +1166,14 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
     for (unsigned pass = 0; pass < npass; ++pass) {
       for (int i = tid; i < size; i += BIG_THREADS) { sh.keys[i] = EMPTY_KEY; sh.vals[i] = 0.f; }
       __syncthreads();
-      for_each_product<BIG_NW, BIG_U, true>(sh.st, as, ae, JA, VA, IB, JB, VB, [&](bool active, int col, float v) {
-        if (active) {
-          // hash class of a column: bits of a second multiplicative hash, independent of the slot hash
-          const bool minePass = npass == 1 || (((unsigned)col * 0x85ebca6bu) >> 12) % npass == pass;
-          if (minePass) {
-            bool isnew;
-            const int s = hash_insert(sh.keys, size, shift, col, &isnew, err);
-            atomicAdd(&sh.vals[s], v);
-          }
-        }
+      for_each_product<BIG_NW, BIG_U, true>(sh.st, as, ae, JA, VA, IB, JB, VB,
+                                            [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&val)[BIG_U]) {
+        // hash class of a column: bits of a second multiplicative hash, independent of the slot hash
+        bool mine[BIG_U];
+#pragma unroll
+        for (int u = 0; u < BIG_U; ++u)
+          mine[u] = act[u] && (npass == 1 || (((unsigned)col[u] * 0x85ebca6bu) >> 12) % npass == pass);
+        hash_insert_multi<BIG_U>(sh.keys, sh.vals, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
       });
       // compaction: wave w sweeps slots [w*per, w*per+per), 64 per step -> coalesced stores
       const int lane = lane_id(), w = tid >> 6;

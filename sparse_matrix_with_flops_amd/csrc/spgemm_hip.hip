@@ -152,6 +152,7 @@ struct spgemm_handle {
   hipEvent_t fork_ev = nullptr;
   hipEvent_t join_ev[NSIDE] = {nullptr, nullptr, nullptr, nullptr};
   bool serial = true;
+  int U = 2;                         // rounds in flight per wave in the hash kernels (SPGEMM_U=2|4|8)
   // column bitmaps of the big rows, saved by the symbolic pass for the rank kernel (n <= BIG_WC).  Sized from
   // the previous calls (the number of big rows is only known on the host after the symbolic phase).
   unsigned* bigBitmaps = nullptr;
@@ -211,6 +212,7 @@ extern "C" int spgemm_hip_create(spgemm_handle** out, int device) {
   for (auto& e : h->kev) HIPCHK(hipEventCreate(&e));
   for (auto& u : h->kused) u = false;
   { const char* e = getenv("SPGEMM_CONCURRENT"); h->serial = !(e && e[0] == '1'); }
+  { const char* e = getenv("SPGEMM_U"); if (e) { const int u = atoi(e); if (u == 2 || u == 4 || u == 8) h->U = u; } }
   for (auto& st : h->side) {
     if (h->serial) st = h->stream;
     else HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -328,6 +330,13 @@ static void join_streams(spgemm_handle* h) {
   }
 }
 
+#define LAUNCH_U(KERN, NW, TBL, grid, block, st, ...)                                              \
+  do {                                                                                             \
+    if (h->U == 8) hipLaunchKernelGGL((KERN<NW, TBL, 8>), grid, block, 0, st, __VA_ARGS__);        \
+    else if (h->U == 4) hipLaunchKernelGGL((KERN<NW, TBL, 4>), grid, block, 0, st, __VA_ARGS__);   \
+    else hipLaunchKernelGGL((KERN<NW, TBL, 2>), grid, block, 0, st, __VA_ARGS__);                  \
+  } while (0)
+
 // flops + bins: K1, K2, K3.  Also presets IC[row] for rows with 0 / 1 products.
 static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, int m, int* dIC) {
   const int nblk = cdiv(m, K1_THREADS);
@@ -361,14 +370,14 @@ static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJA, con
     hipLaunchKernelGGL(k_sym_big, dim3(clampi(m, 1, cu)), dim3(BIG_THREADS), sizeof(BigSymShared), st, bp, 8,
                        rowIds, dIA, dJA, dIB, dJB, n, dIC, h->bigBitmaps, h->bm_cap, qc + 0); }
   { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_SYM_HASH8, st);
-    hipLaunchKernelGGL((k_sym_hash<8, 8192, 2>), dim3(clampi(m, 1, cu * 3)), dim3(512), 0, st, bp, 7, rowIds, dIA,
-                       dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 1); }
+    LAUNCH_U(k_sym_hash, 8, 8192, dim3(clampi(m, 1, cu * 3)), dim3(512), st, bp, 7, rowIds, dIA,
+             dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 1); }
   { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_SYM_HASH4, st);
-    hipLaunchKernelGGL((k_sym_hash<4, 4096, 2>), dim3(clampi(m, 1, cu * 8)), dim3(256), 0, st, bp, 6, rowIds, dIA,
-                       dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 2); }
+    LAUNCH_U(k_sym_hash, 4, 4096, dim3(clampi(m, 1, cu * 8)), dim3(256), st, bp, 6, rowIds, dIA,
+             dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 2); }
   { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_SYM_HASH1, st);
-    hipLaunchKernelGGL((k_sym_hash<1, 1024, 2>), dim3(clampi(m, 1, cu * 32)), dim3(64), 0, st, bp, 5, rowIds, dIA,
-                       dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 3); }
+    LAUNCH_U(k_sym_hash, 1, 1024, dim3(clampi(m, 1, cu * 32)), dim3(64), st, bp, 5, rowIds, dIA,
+             dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 3); }
   { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_SYM_G16, st);
     hipLaunchKernelGGL((k_sym_g16<128, 4>), dim3(clampi(cdiv(m, 16), 1, cu * 16)), dim3(256), 0, st, bp, 4,
                        rowIds, dIA, dJA, dIB, dJB, h->rowFlops, dIC, err); }
@@ -411,14 +420,14 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const int* dJA, cons
                          bp, 8, rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 4); }
   }
   if (rows(7, 8) > 0) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_NUM_HASH8, st);
-    hipLaunchKernelGGL((k_num_hash<8, 8192, 2>), dim3(clampi(rows(7, 8), 1, cu * 2)), dim3(512), 0, st, bp, 7,
-                       rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 5); }
+    LAUNCH_U(k_num_hash, 8, 8192, dim3(clampi(rows(7, 8), 1, cu * 2)), dim3(512), st, bp, 7,
+             rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 5); }
   if (rows(6, 7) > 0) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_NUM_HASH4, st);
-    hipLaunchKernelGGL((k_num_hash<4, 4096, 2>), dim3(clampi(rows(6, 7), 1, cu * 4)), dim3(256), 0, st, bp, 6,
-                       rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 6); }
+    LAUNCH_U(k_num_hash, 4, 4096, dim3(clampi(rows(6, 7), 1, cu * 4)), dim3(256), st, bp, 6,
+             rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 6); }
   if (rows(5, 6) > 0) { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_NUM_HASH1, st);
-    hipLaunchKernelGGL((k_num_hash<1, 1024, 2>), dim3(clampi(rows(5, 6), 1, cu * 16)), dim3(64), 0, st, bp, 5,
-                       rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 7); }
+    LAUNCH_U(k_num_hash, 1, 1024, dim3(clampi(rows(5, 6), 1, cu * 16)), dim3(64), st, bp, 5,
+             rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 7); }
   if (rows(4, 5) > 0) { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_NUM_G16, st);
     hipLaunchKernelGGL((k_num_g16<128, 4>), dim3(clampi(cdiv(rows(4, 5), 16), 1, cu * 16)), dim3(256), 0, st,
                        bp, 4, rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err); }
@@ -810,3 +819,13 @@ extern "C" int spgemm_hip_selftest(spgemm_handle* h) {
   if (bad != 0) return fail(SPGEMM_ERR_INTERNAL, "wave primitive self-test: %d lanes disagree", bad);
   return SPGEMM_OK;
 }
+
+#ifdef SMF_STAMPS
+// diagnostic build only: read and clear the per-phase cycle sums
+extern "C" int spgemm_hip_debug_stamps(unsigned long long* out /*[4][16]*/, int clear) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(smf::g_stamps), sizeof(unsigned long long) * 64));
+  if (clear) { unsigned long long z[64] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(smf::g_stamps), z, sizeof(z))); }
+  return SPGEMM_OK;
+}
+#endif
