@@ -156,6 +156,20 @@ int hip_sgpuSpMM(spgemm_handle* h,
                  const int* drowIds, const int hv[SPGEMM_HV_LEN], const int* dflops,
                  int** dIC, int** dJC, float** dC, int* nnzC);
 
+/* ---- R-MCL (the caller of the path) --------------------------------------
+ * hip_rmcl_prune: the post-step of one iteration on device arrays: inflate / threshold-prune / normalise every row of
+ * C (dIC[m+1], dJC, dC; dC is squared in place) and compact into new arrays (*dIN, *dJN, *dCN allocated here, release
+ * with spgemm_hip_free).  CPU: nlibs/qrmcl.cc:96-117 + nlibs/tools/util.cc:4-69; reference GPU: nlibs/gpus/dutil.cuh.
+ * hip_gpuRmclIter: void gpuRmclIter(const int maxIter, const CSR Mgt, CSR& Mt) (nlibs/gpus/gpu_csr_kernel.cu:281-311):
+ * host CSRs in; Mt <- prune(Mgt * Mt) maxIter times; the new Mt comes back in malloc()ed arrays (the caller disposes
+ * the old ones). */
+int hip_rmcl_prune(spgemm_handle* h, int m, const int* dIC, const int* dJC, float* dC,
+                   int** dIN, int** dJN, float** dCN, int* nnzN);
+int hip_gpuRmclIter(int maxIter, int rows, int cols,
+                    const int* gIA, const int* gJA, const float* gA, int gnnz,
+                    const int* tIA, const int* tJA, const float* tA, int tnnz,
+                    int** oIA, int** oJA, float** oA, int* onnz);
+
 /* ---- helpers the reference's drivers use around the path --------------------------------------- */
 /* CSR::makeOrdered on device arrays (nlibs/CSR.cc:73-86): sort every row by column, in place. */
 int hip_csr_sort_rows(spgemm_handle* h, int m, const int* dIC, int* dJC, float* dC);

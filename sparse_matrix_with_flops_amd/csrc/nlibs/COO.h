@@ -1,0 +1,24 @@
+// COO.h — mirror of the reference's `class COO` (nlibs/COO.h:6-26): triplet arrays + the text loaders and the
+// sort / dedupe / toCSR steps every driver runs before the SpGEMM path.
+#ifndef SMF_COO_H_
+#define SMF_COO_H_
+#include "CSR.h"
+
+class COO {
+ public:
+  int* cooRowIndex;
+  int* cooColIndex;
+  QValue* cooVal;
+  int rows, cols, nnz;
+  COO() : cooRowIndex(0), cooColIndex(0), cooVal(0), rows(0), cols(0), nnz(0) {}
+  void dispose();
+  // SNAP edge lists and MatrixMarket coordinate files (nlibs/COO.cc:48-158): '#'/'%' comment lines, then a size line
+  // "rows nnz" or "rows cols nnz", then "from to [value]" lines; a 5-token '%' banner marks MatrixMarket (1-based
+  // indices, "symmetric" expands (i,j)->(j,i)); isTrans reads the transpose (what R-MCL wants).
+  int readSNAPFile(const char fname[], bool isTrans = true);
+  void addSelfLoopIfNeeded();           // nlibs/COO.cc:160-188
+  void makeOrdered() const;             // nlibs/COO.cc:222-235: sort by (row, col)
+  int orderedAndDuplicatesRemoving();   // nlibs/COO.cc:237-266: sort + sum duplicates
+  CSR toCSR() const;                    // nlibs/COO.cc:268-291 (input must be ordered)
+};
+#endif

@@ -1,0 +1,210 @@
+// CSR.cc — see CSR.h.  Host-side glue only; products are computed by libspgemm_hip.so.
+#include "CSR.h"
+#include "gpus/gpu_csr_kernel.h"
+#include "../../../include/spgemm_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+static void* must_malloc(size_t bytes, const char* what) {
+  void* p = malloc(bytes ? bytes : 1);
+  if (!p) { printf("out of host memory allocating %s (%zu bytes)\n", what, bytes); exit(EXIT_FAILURE); }
+  return p;
+}
+
+static void hip_or_die(int rc, const char* what) {
+  if (rc != SPGEMM_OK) { printf("%s: %s\n", what, spgemm_hip_last_error()); exit(EXIT_FAILURE); }
+}
+
+CSR CSR::deepCopy() const {
+  int* rp = (int*)must_malloc(sizeof(int) * ((size_t)rows + 1), "rowPtr");
+  int* ci = (int*)must_malloc(sizeof(int) * (size_t)nnz, "colInd");
+  QValue* v = (QValue*)must_malloc(sizeof(QValue) * (size_t)nnz, "values");
+  memcpy(rp, rowPtr, sizeof(int) * ((size_t)rows + 1));
+  memcpy(ci, colInd, sizeof(int) * (size_t)nnz);
+  memcpy(v, values, sizeof(QValue) * (size_t)nnz);
+  return CSR(v, ci, rp, rows, cols, nnz);
+}
+
+void CSR::makeOrdered() {
+  std::vector<std::pair<int, QValue> > row;
+  for (int i = 0; i < rows; ++i) {
+    const int s = rowPtr[i], e = rowPtr[i + 1];
+    if (e - s < 2) continue;
+    row.resize(e - s);
+    for (int p = s; p < e; ++p) row[p - s] = std::make_pair(colInd[p], values[p]);
+    std::sort(row.begin(), row.end());
+    for (int p = s; p < e; ++p) { colInd[p] = row[p - s].first; values[p] = row[p - s].second; }
+  }
+}
+
+void CSR::toAbs() { for (int p = 0; p < nnz; ++p) values[p] = std::fabs(values[p]); }
+
+void CSR::averAndNormRowQValue() {
+  for (int i = 0; i < rows; ++i) {
+    const int count = rowPtr[i + 1] - rowPtr[i];
+    for (int p = rowPtr[i]; p < rowPtr[i + 1]; ++p) values[p] = (QValue)(1.0 / count);
+  }
+}
+
+void CSR::dispose() {
+  free(values); values = 0;
+  free(colInd); colInd = 0;
+  free(rowPtr); rowPtr = 0;
+}
+
+void CSR::output(const char* msg) const {
+  printf("%s\n", msg);
+  for (int i = 0; i < rows; ++i)
+    for (int p = rowPtr[i]; p < rowPtr[i + 1]; ++p) printf("%d\t%d\t%.6lf\n", i, colInd[p], (double)values[p]);
+}
+
+bool CSR::isEqual(const CSR& B) const {
+  bool same = true;
+  if (rows != B.rows) { printf("rows = %d\tB_rows = %d\n", rows, B.rows); same = false; }
+  if (cols != B.cols) { printf("cols = %d\tB_cols = %d\n", cols, B.cols); same = false; }
+  if (nnz != B.nnz) { printf("nnz = %d\tB_nnz = %d\n", nnz, B.nnz); same = false; }
+  if (!same) return false;
+  for (int i = 0; i <= rows; ++i)
+    if (rowPtr[i] != B.rowPtr[i]) { printf("rowPtr[%d] %d\t%d\n", i, rowPtr[i], B.rowPtr[i]); return false; }
+  std::vector<double> dense((size_t)cols, 0.0);
+  for (int i = 0; i < rows; ++i) {
+    for (int p = rowPtr[i]; p < rowPtr[i + 1]; ++p) dense[colInd[p]] = values[p];
+    for (int p = B.rowPtr[i]; p < B.rowPtr[i + 1]; ++p) {
+      const int c = B.colInd[p];
+      if (std::fabs(dense[c] - B.values[p]) > 1e-7) {
+        printf("values[%d][%d] %lf\t%lf\n", i, c, dense[c], (double)B.values[p]);
+        return false;
+      }
+      dense[c] = 0.0;
+    }
+  }
+  return true;
+}
+
+bool CSR::isParityEqual(const CSR& B, double rel) const {
+  if (rows != B.rows || cols != B.cols || nnz != B.nnz) return false;
+  if (memcmp(rowPtr, B.rowPtr, sizeof(int) * ((size_t)rows + 1)) != 0) return false;
+  if (memcmp(colInd, B.colInd, sizeof(int) * (size_t)nnz) != 0) return false;
+  for (int p = 0; p < nnz; ++p) {
+    const double x = values[p], y = B.values[p];
+    if (std::fabs(x - y) > rel * std::max(std::fabs(x), std::fabs(y))) {
+      printf("values[%d] %.9e\t%.9e\n", p, x, y);
+      return false;
+    }
+  }
+  return true;
+}
+
+CSR CSR::toGpuCSR() const {
+  CSR d;
+  d.rows = rows; d.cols = cols; d.nnz = nnz;
+  hip_or_die(spgemm_hip_malloc((void**)&d.rowPtr, sizeof(int) * ((size_t)rows + 1)), "toGpuCSR");
+  hip_or_die(spgemm_hip_memcpy_h2d(d.rowPtr, rowPtr, sizeof(int) * ((size_t)rows + 1)), "toGpuCSR");
+  hip_or_die(spgemm_hip_malloc((void**)&d.colInd, sizeof(int) * (size_t)nnz), "toGpuCSR");
+  hip_or_die(spgemm_hip_memcpy_h2d(d.colInd, colInd, sizeof(int) * (size_t)nnz), "toGpuCSR");
+  hip_or_die(spgemm_hip_malloc((void**)&d.values, sizeof(QValue) * (size_t)nnz), "toGpuCSR");
+  hip_or_die(spgemm_hip_memcpy_h2d(d.values, values, sizeof(QValue) * (size_t)nnz), "toGpuCSR");
+  return d;
+}
+
+CSR CSR::toCpuCSR() const {
+  CSR h;
+  h.rows = rows; h.cols = cols; h.nnz = nnz;
+  h.rowPtr = (int*)must_malloc(sizeof(int) * ((size_t)rows + 1), "rowPtr");
+  h.colInd = (int*)must_malloc(sizeof(int) * (size_t)nnz, "colInd");
+  h.values = (QValue*)must_malloc(sizeof(QValue) * (size_t)nnz, "values");
+  hip_or_die(spgemm_hip_memcpy_d2h(h.rowPtr, rowPtr, sizeof(int) * ((size_t)rows + 1)), "toCpuCSR");
+  hip_or_die(spgemm_hip_memcpy_d2h(h.colInd, colInd, sizeof(int) * (size_t)nnz), "toCpuCSR");
+  hip_or_die(spgemm_hip_memcpy_d2h(h.values, values, sizeof(QValue) * (size_t)nnz), "toCpuCSR");
+  return h;
+}
+
+void CSR::deviceDispose() {
+  spgemm_hip_free(values); values = 0;
+  spgemm_hip_free(colInd); colInd = 0;
+  spgemm_hip_free(rowPtr); rowPtr = 0;
+}
+
+CSR CSR::hip_spmm(const CSR& B, const int stride) const {
+  if (cols != B.rows) { printf("hip_spmm: A is %dx%d but B is %dx%d\n", rows, cols, B.rows, B.cols); exit(EXIT_FAILURE); }
+  int *IC = 0, *JC = 0, nnzC = 0;
+  QValue* C = 0;
+  hip_CSR_SpMM(rowPtr, colInd, values, nnz, B.rowPtr, B.colInd, B.values, B.nnz, IC, JC, C, nnzC, rows, cols, B.cols, stride);
+  return CSR(C, JC, IC, rows, B.cols, nnzC);
+}
+
+long long CSR::spMMFlops(const CSR& B) const {
+  long long p = 0;
+  for (int q = 0; q < nnz; ++q) { const int j = colInd[q]; p += B.rowPtr[j + 1] - B.rowPtr[j]; }
+  return 2 * p;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wrapper functions (gpus/gpu_csr_kernel.h)
+// ---------------------------------------------------------------------------------------------------------------
+void hip_CSR_SpMM(const int IA[], const int JA[], const QValue A[], const int nnzA, const int IB[], const int JB[],
+                  const QValue B[], const int nnzB, int*& IC, int*& JC, QValue*& C, int& nnzC, const int m,
+                  const int k, const int n, const int stride) {
+  (void)stride;
+  hip_or_die(::hip_CSR_SpMM(IA, JA, A, nnzA, IB, JB, B, nnzB, &IC, &JC, &C, &nnzC, m, k, n), "hip_CSR_SpMM");
+}
+
+CSR gpuSpMMWrapper(const CSR& dA, const CSR& dB) {
+  if (dA.cols != dB.rows) { printf("gpuSpMMWrapper: shape mismatch\n"); exit(EXIT_FAILURE); }
+  CSR dC;
+  hip_or_die(hip_gpuSpMM(0, dA.rowPtr, dA.colInd, dA.values, dA.nnz, dB.rowPtr, dB.colInd, dB.values, dB.nnz, dA.rows,
+                         dA.cols, dB.cols, &dC.rowPtr, &dC.colInd, &dC.values, &dC.nnz), "gpuSpMMWrapper");
+  dC.rows = dA.rows;
+  dC.cols = dB.cols;
+  return dC;
+}
+
+std::vector<int> gpuFlopsClassify(const CSR& dA, const CSR& dB, int** drowIdsp, int** dflopId) {
+  int hv[SPGEMM_HV_LEN], len = 0;
+  long long total = 0;
+  hip_or_die(hip_gpuFlopsClassify(0, dA.rowPtr, dA.colInd, dB.rowPtr, dA.rows, dA.cols, drowIdsp, dflopId, hv, &len, &total),
+             "gpuFlopsClassify");
+  return std::vector<int>(hv, hv + len);      // the reference's vector has max bin + 2 entries
+}
+
+CSR sgpuSpMMWrapper(const CSR& dA, const CSR& dB, int* drowIds, const std::vector<int>& hv, int* dflops) {
+  int full[SPGEMM_HV_LEN];
+  for (int i = 0; i < SPGEMM_HV_LEN; ++i) full[i] = i < (int)hv.size() ? hv[i] : (hv.empty() ? 0 : hv.back());
+  CSR dC;
+  hip_or_die(hip_sgpuSpMM(0, dA.rowPtr, dA.colInd, dA.values, dA.nnz, dB.rowPtr, dB.colInd, dB.values, dB.nnz, dA.rows,
+                          dA.cols, dB.cols, drowIds, full, dflops, &dC.rowPtr, &dC.colInd, &dC.values, &dC.nnz),
+             "sgpuSpMMWrapper");
+  dC.rows = dA.rows;
+  dC.cols = dB.cols;
+  return dC;
+}
+
+CSR scudaSpMM(const CSR& hA, const CSR& hB) {
+  CSR dA = hA.toGpuCSR();
+  CSR dB = hB.toGpuCSR();
+  int *dqueue = 0, *dflops = 0;
+  std::vector<int> hv = gpuFlopsClassify(dA, dB, &dqueue, &dflops);
+  CSR dC = sgpuSpMMWrapper(dA, dB, dqueue, hv, dflops);
+  CSR hC = dC.toCpuCSR();
+  dC.deviceDispose();
+  spgemm_hip_free(dqueue);
+  spgemm_hip_free(dflops);
+  dA.deviceDispose();
+  dB.deviceDispose();
+  return hC;
+}
+
+void gpuRmclIter(const int maxIter, const CSR Mgt, CSR& Mt) {
+  int *oI = 0, *oJ = 0, on = 0;
+  QValue* oA = 0;
+  hip_or_die(hip_gpuRmclIter(maxIter, Mt.rows, Mt.cols, Mgt.rowPtr, Mgt.colInd, Mgt.values, Mgt.nnz, Mt.rowPtr, Mt.colInd,
+                             Mt.values, Mt.nnz, &oI, &oJ, &oA, &on), "gpuRmclIter");
+  Mt.dispose();                                   // nlibs/gpus/gpu_csr_kernel.cu:302-303: old arrays freed, new malloc()ed
+  Mt.init(oA, oJ, oI, Mgt.rows, Mgt.cols, on);
+}

@@ -1,0 +1,24 @@
+// gpu_csr_kernel.h — the GPU call surface the reference's drivers link, re-hosted on libspgemm_hip.so.
+//   gpuSpMMWrapper / gpuRmclIter          nlibs/gpus/gpu_csr_kernel.h:5-6 (.cu:128-173, :281-311)
+//   gpuFlopsClassify / sgpuSpMMWrapper /
+//   scudaSpMM                             mindex2-cuda/nGpuSpMM.cc:19,242,245
+//   hip_CSR_SpMM (reference-style refs)   the *_CSR_SpMM family, nlibs/cpu_csr_kernel.h:63-102
+// Errors: like HANDLE_ERROR (nlibs/gpus/cuda_handle_error.h:7-15) these wrappers print and exit(EXIT_FAILURE);
+// use the C ABI (include/spgemm_hip.h) directly for status codes.
+#ifndef SMF_GPU_CSR_KERNEL_H_
+#define SMF_GPU_CSR_KERNEL_H_
+#include <vector>
+#include "../CSR.h"
+
+CSR gpuSpMMWrapper(const CSR& dA, const CSR& dB);
+std::vector<int> gpuFlopsClassify(const CSR& dA, const CSR& dB, int** drowIdsp, int** dflopId);
+CSR sgpuSpMMWrapper(const CSR& dA, const CSR& dB, int* drowIds, const std::vector<int>& hv, int* dflops);
+CSR scudaSpMM(const CSR& hA, const CSR& hB);
+void gpuRmclIter(const int maxIter, const CSR Mgt, CSR& Mt);
+
+// raw arrays, the signature every CPU kernel of the reference has
+void hip_CSR_SpMM(const int IA[], const int JA[], const QValue A[], const int nnzA,
+                  const int IB[], const int JB[], const QValue B[], const int nnzB,
+                  int*& IC, int*& JC, QValue*& C, int& nnzC,
+                  const int m, const int k, const int n, const int stride = 512);
+#endif

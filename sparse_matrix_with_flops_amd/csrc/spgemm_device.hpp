@@ -134,7 +134,9 @@ __device__ __forceinline__ int hash_insert(int* keys, int size, int shift, int c
 // own exec-mask branch with an s_waitcnt right behind it.  CAS first: most products of a SpGEMM row touch their
 // column for the first time, so the claim usually succeeds in one LDS round trip.
 // vals == nullptr: symbolic (count only).  `dummy` = one private int per lane.  Returns the slots this lane claimed.
-template <int U>
+// POW2: size is a power of two (slot = top bits of the multiplicative hash); otherwise any size
+// (slot = mulhi(hash, size)), which lets the big-row kernel use every byte of LDS it can get.
+template <int U, bool POW2 = true>
 __device__ __forceinline__ int hash_insert_multi(int* keys, float* vals, int size, int shift, const bool (&act)[U],
                                                  const int (&col)[U], const float (&val)[U], int* dummy, int* err) {
   const unsigned mask = (unsigned)size - 1u;
@@ -142,7 +144,11 @@ __device__ __forceinline__ int hash_insert_multi(int* keys, float* vals, int siz
   bool pend[U];
   int claimed = 0;
 #pragma unroll
-  for (int u = 0; u < U; ++u) { h[u] = ((unsigned)col[u] * 2654435761u) >> shift; pend[u] = act[u]; }
+  for (int u = 0; u < U; ++u) {
+    const unsigned hv = (unsigned)col[u] * 2654435761u;
+    h[u] = POW2 ? hv >> shift : __umulhi(hv, (unsigned)size);
+    pend[u] = act[u];
+  }
   bool done = false;
   for (int probe = 0; probe < size && !done; ++probe) {
     int old[U];
@@ -154,7 +160,8 @@ __device__ __forceinline__ int hash_insert_multi(int* keys, float* vals, int siz
       const bool fresh = pend[u] && old[u] == EMPTY_KEY;
       const bool fin = fresh || old[u] == col[u];
       claimed += fresh ? 1 : 0;
-      h[u] = (pend[u] && !fin) ? ((h[u] + 1u) & mask) : h[u];
+      const unsigned nh = POW2 ? ((h[u] + 1u) & mask) : (h[u] + 1u == (unsigned)size ? 0u : h[u] + 1u);
+      h[u] = (pend[u] && !fin) ? nh : h[u];
       pend[u] = pend[u] && !fin;
       more = more || pend[u];
     }
@@ -935,8 +942,8 @@ constexpr int BIG_WC = 262144;                 // columns covered by the rank ke
 constexpr int BIG_WORDS = BIG_WC / 32;         // 8192
 constexpr int BIG_WPT = BIG_WORDS / BIG_THREADS;  // 8 words per thread
 constexpr int BIG_CAP = 18432;                 // float accumulators per rank pass (72 KB)
-constexpr int BH_SLOTS = 16384;                // hash kernel: 64 KB keys + 64 KB values
-constexpr int BH_CAP = 9216;                   // distinct columns per hash pass (load <= 0.56 + partition skew)
+constexpr int BH_SLOTS = 17408;                // hash kernel: 68 KB keys + 68 KB values (17 x 1024 slots, not a power of two)
+constexpr int BH_CAP = 12800;                  // distinct columns per hash pass (load <= 0.74 incl. partition skew)
 
 struct BigSymShared {
   unsigned bitmap[SYM_WORDS];
@@ -1160,8 +1167,10 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
     const int outEnd = IC[row + 1];
     const int want = outEnd - outBase;
     const unsigned npass = (unsigned)((want + BH_CAP - 1) / BH_CAP);
-    const int size = npass > 1 ? BH_SLOTS : next_pow2_clamped(2 * want, BIG_THREADS, BH_SLOTS);
-    const int shift = 32 - log2_pow2(size);
+    // any multiple of 1024 slots (64 per wave-step): twice the distinct columns of a pass when that fits
+    const int perPass = (want + (int)npass - 1) / (int)npass;
+    const int size = min(BH_SLOTS, max(BIG_THREADS, (2 * perPass + BIG_THREADS - 1) / BIG_THREADS * BIG_THREADS));
+    const int shift = 0;
     const int per = size / BIG_NW;
     for (unsigned pass = 0; pass < npass; ++pass) {
       for (int i = tid; i < size; i += BIG_THREADS) { sh.keys[i] = EMPTY_KEY; sh.vals[i] = 0.f; }
@@ -1173,7 +1182,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
 #pragma unroll
         for (int u = 0; u < BIG_U; ++u)
           mine[u] = act[u] && (npass == 1 || (((unsigned)col[u] * 0x85ebca6bu) >> 12) % npass == pass);
-        hash_insert_multi<BIG_U>(sh.keys, sh.vals, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
+        hash_insert_multi<BIG_U, false>(sh.keys, sh.vals, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
       });
       // compaction: wave w sweeps slots [w*per, w*per+per), 64 per step -> coalesced stores
       const int lane = lane_id(), w = tid >> 6;
@@ -1333,6 +1342,82 @@ __global__ __launch_bounds__(256) void k_sort_rows(int m, const int* __restrict_
         __threadfence();
         __syncthreads();
       }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// R-MCL post-step (the step right after the SpGEMM in the reference's loop):
+// per row of C: inflate (square), max, sum, thresh = clamp(0.9*avg*(1-2(max-avg)), 1e-7, max), keep v >= thresh,
+// divide the kept values by their sum, compact.  CPU: nlibs/tools/util.cc:4-69, nlibs/qrmcl.cc:96-117;
+// reference GPU: nlibs/gpus/dutil.cuh:8-80 + thrust::remove (gpu_csr_kernel.cu:218-229,265-270).
+// 16 lanes per row (4 rows per wave).  Sums are 16-lane tree reductions in float, so a value that sits within an
+// ulp of the threshold can fall on the other side than in the sequential CPU loop (the reference's own GPU path
+// has the same property).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rmcl_threshold(float avg, float mx) {
+  float ret = (float)(0.90 * avg * (1 - 2 * (mx - avg)));       // same promotions as computeThreshold (util.cc:4-9)
+  ret = (float)((ret > 1.0e-7) ? ret : 1.0e-7);
+  ret = (ret > mx) ? mx : ret;
+  return ret;
+}
+
+__device__ __forceinline__ float row16_sum(float v) {
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 16));
+  return v;
+}
+
+// pass 1: squares in place, per-row threshold and kept sum, kept count -> cnt[row]
+__global__ __launch_bounds__(256) void k_rmcl_stats(int m, const int* __restrict__ IC, float* __restrict__ C,
+                                                     int* __restrict__ cnt, float* __restrict__ thresh,
+                                                     float* __restrict__ ksum) {
+  const int gl = threadIdx.x & 15;
+  const int nrows16 = (m + 15) / 16 * 16;
+  for (int row = (blockIdx.x * 256 + threadIdx.x) >> 4; row < nrows16; row += (gridDim.x * 256) >> 4) {
+    const bool live = row < m;
+    const int s = live ? IC[row] : 0, e = live ? IC[row + 1] : 0;
+    float mx = 0.f, sum = 0.f;
+    for (int p = s + gl; p < e; p += 16) { const float v = C[p] * C[p]; C[p] = v; mx = fmaxf(mx, v); sum += v; }
+    mx = row16_max(mx);
+    sum = row16_sum(sum);
+    const float th = rmcl_threshold(sum / (float)(e - s), mx);
+    float ks = 0.f;
+    int kc = 0;
+    for (int p = s + gl; p < e; p += 16) { const float v = C[p]; if (v >= th) { ks += v; ++kc; } }
+    ks = row16_sum(ks);
+    kc = (int)row16_sum((float)kc);
+    if (live && gl == 0) { cnt[row] = kc; thresh[row] = th; ksum[row] = ks; }
+  }
+}
+
+// pass 2: stable compaction of the kept entries, normalised, into the new arrays at newPtr[row]
+__global__ __launch_bounds__(256) void k_rmcl_compact(int m, const int* __restrict__ IC, const int* __restrict__ JC,
+                                                       const float* __restrict__ C, const int* __restrict__ newPtr,
+                                                       const float* __restrict__ thresh, const float* __restrict__ ksum,
+                                                       int* __restrict__ JN, float* __restrict__ CN) {
+  const int gl = threadIdx.x & 15;
+  const int lane = lane_id();
+  const int nrows16 = (m + 15) / 16 * 16;
+  for (int row = (blockIdx.x * 256 + threadIdx.x) >> 4; row < nrows16; row += (gridDim.x * 256) >> 4) {
+    const bool live = row < m;
+    const int s = live ? IC[row] : 0, e = live ? IC[row + 1] : 0;
+    const float th = live ? thresh[row] : 0.f, ks = live ? ksum[row] : 1.f;
+    int out = live ? newPtr[row] : 0;
+    for (int p0 = s; p0 < e; p0 += 16) {
+      const int p = p0 + gl;
+      const float v = p < e ? C[p] : 0.f;
+      const bool keep = p < e && v >= th;
+      const unsigned long long mk = __ballot(keep);
+      const unsigned gm = (unsigned)(mk >> (lane - gl)) & 0xffffu;
+      if (keep) { const int o = out + __popc(gm & ((1u << gl) - 1u)); JN[o] = JC[p]; CN[o] = v / ks; }
+      out += __popc(gm);
     }
   }
 }

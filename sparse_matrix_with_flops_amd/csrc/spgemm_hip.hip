@@ -782,6 +782,94 @@ extern "C" int hip_CSR_SpMM(const int* IA, const int* JA, const float* A, int nn
 }
 
 // ------------------------------------------------------------------------------------------------
+// R-MCL
+// ------------------------------------------------------------------------------------------------
+extern "C" int hip_rmcl_prune(spgemm_handle* h, int m, const int* dIC, const int* dJC, float* dC, int** dIN, int** dJN,
+                              float** dCN, int* nnzN) {
+  if (!dIN || !dJN || !dCN || !nnzN) return fail(SPGEMM_ERR_ARG, "output pointer is null");
+  *dIN = nullptr; *dJN = nullptr; *dCN = nullptr; *nnzN = 0;
+  if (m < 0 || !dIC) return fail(SPGEMM_ERR_ARG, "bad argument");
+  if (!h) CHK(default_handle(&h));
+  HIPCHK(hipSetDevice(h->device));
+  CHK(ws_ensure(h, m));
+  int* newPtr = nullptr; int* JN = nullptr; float* CN = nullptr; float* th = nullptr; float* ks = nullptr;
+  auto cleanup = [&](int rc) { pool().release(newPtr); pool().release(JN); pool().release(CN); pool().release(th); pool().release(ks); return rc; };
+  if (hipSuccess != pool().alloc((void**)&newPtr, sizeof(int) * ((size_t)m + 1)) ||
+      hipSuccess != pool().alloc((void**)&th, sizeof(float) * (size_t)std::max(m, 1)) ||
+      hipSuccess != pool().alloc((void**)&ks, sizeof(float) * (size_t)std::max(m, 1)))
+    return cleanup(fail(SPGEMM_ERR_HIP, "device allocation failed"));
+  hipStream_t s = h->stream;
+  HIPCHK(hipMemsetAsync(&h->dsmall->nnzC64, 0, sizeof(unsigned long long), s));
+  const int grid = clampi(cdiv(m, 16), 1, h->numCU * 16);
+  if (m > 0) {
+    hipLaunchKernelGGL(k_rmcl_stats, dim3(grid), dim3(256), 0, s, m, dIC, dC, newPtr, th, ks);
+    int rc = launch_scan(h, newPtr, m, &h->dsmall->nnzC64);
+    if (rc) return cleanup(rc);
+  } else {
+    hipMemsetAsync(newPtr, 0, sizeof(int), s);
+  }
+  if (hipMemcpyAsync(&h->hsmall->nnzC64, &h->dsmall->nnzC64, sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return cleanup(fail(SPGEMM_ERR_HIP, "rmcl prune failed: %s", hipGetErrorString(hipGetLastError())));
+  const int nz = (int)h->hsmall->nnzC64;
+  if (hipSuccess != pool().alloc((void**)&JN, sizeof(int) * (size_t)std::max(nz, 1)) ||
+      hipSuccess != pool().alloc((void**)&CN, sizeof(float) * (size_t)std::max(nz, 1)))
+    return cleanup(fail(SPGEMM_ERR_HIP, "device allocation failed"));
+  if (m > 0 && nz > 0) {
+    hipLaunchKernelGGL(k_rmcl_compact, dim3(grid), dim3(256), 0, s, m, dIC, dJC, dC, newPtr, th, ks, JN, CN);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  pool().release(th); pool().release(ks);
+  *dIN = newPtr; *dJN = JN; *dCN = CN; *nnzN = nz;
+  return SPGEMM_OK;
+}
+
+extern "C" int hip_gpuRmclIter(int maxIter, int rows, int cols, const int* gIA, const int* gJA, const float* gA, int gnnz,
+                               const int* tIA, const int* tJA, const float* tA, int tnnz, int** oIA, int** oJA,
+                               float** oA, int* onnz) {
+  if (!oIA || !oJA || !oA || !onnz) return fail(SPGEMM_ERR_ARG, "output pointer is null");
+  if (rows < 0 || cols != rows || maxIter < 0) return fail(SPGEMM_ERR_ARG, "R-MCL needs a square matrix and maxIter >= 0");
+  CHK(check_common(gIA, gJA, gA, gnnz, "Mgt"));
+  CHK(check_common(tIA, tJA, tA, tnnz, "Mt"));
+  CHK(validate_host_csr(gIA, gJA, rows, cols, gnnz, "Mgt"));
+  CHK(validate_host_csr(tIA, tJA, rows, cols, tnnz, "Mt"));
+  spgemm_handle* h = nullptr;
+  CHK(default_handle(&h));
+  int *dgI = nullptr, *dgJ = nullptr, *dtI = nullptr, *dtJ = nullptr;
+  float *dgA = nullptr, *dtA = nullptr;
+  auto cleanup = [&](int rc) { for (void* p : {(void*)dgI, (void*)dgJ, (void*)dgA, (void*)dtI, (void*)dtJ, (void*)dtA}) pool().release(p); return rc; };
+  int rc;
+#define UP(dst, src, bytes) \
+  if ((rc = spgemm_hip_malloc((void**)&dst, (bytes))) || (rc = spgemm_hip_memcpy_h2d(dst, src, (bytes)))) return cleanup(rc);
+  UP(dgI, gIA, sizeof(int) * ((size_t)rows + 1)); UP(dgJ, gJA, sizeof(int) * (size_t)gnnz); UP(dgA, gA, sizeof(float) * (size_t)gnnz);
+  UP(dtI, tIA, sizeof(int) * ((size_t)rows + 1)); UP(dtJ, tJA, sizeof(int) * (size_t)tnnz); UP(dtA, tA, sizeof(float) * (size_t)tnnz);
+#undef UP
+  int curnnz = tnnz;
+  for (int it = 0; it < maxIter; ++it) {
+    int *cI = nullptr, *cJ = nullptr, cn = 0;
+    float* cA = nullptr;
+    if ((rc = hip_gpuSpMM(h, dgI, dgJ, dgA, gnnz, dtI, dtJ, dtA, curnnz, rows, cols, cols, &cI, &cJ, &cA, &cn))) return cleanup(rc);
+    int *nI = nullptr, *nJ = nullptr, nn = 0;
+    float* nA = nullptr;
+    rc = hip_rmcl_prune(h, rows, cI, cJ, cA, &nI, &nJ, &nA, &nn);
+    pool().release(cI); pool().release(cJ); pool().release(cA);
+    if (rc) return cleanup(rc);
+    pool().release(dtI); pool().release(dtJ); pool().release(dtA);
+    dtI = nI; dtJ = nJ; dtA = nA; curnnz = nn;
+  }
+  int* hI = (int*)malloc(sizeof(int) * ((size_t)rows + 1));
+  int* hJ = (int*)malloc(sizeof(int) * (size_t)std::max(curnnz, 1));
+  float* hA = (float*)malloc(sizeof(float) * (size_t)std::max(curnnz, 1));
+  if (!hI || !hJ || !hA) { free(hI); free(hJ); free(hA); return cleanup(fail(SPGEMM_ERR_NOMEM, "host malloc failed")); }
+  if ((rc = spgemm_hip_memcpy_d2h(hI, dtI, sizeof(int) * ((size_t)rows + 1))) ||
+      (rc = spgemm_hip_memcpy_d2h(hJ, dtJ, sizeof(int) * (size_t)curnnz)) ||
+      (rc = spgemm_hip_memcpy_d2h(hA, dtA, sizeof(float) * (size_t)curnnz))) { free(hI); free(hJ); free(hA); return cleanup(rc); }
+  *oIA = hI; *oJA = hJ; *oA = hA; *onnz = curnnz;
+  return cleanup(SPGEMM_OK);
+}
+
+// ------------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------------
 extern "C" int hip_csr_sort_rows(spgemm_handle* h, int m, const int* dIC, int* dJC, float* dC) {

@@ -33,6 +33,7 @@ EXPORTS = [
     "spgemm_hip_memcpy_h2d", "spgemm_hip_memcpy_d2h", "hip_CSR_SpMM", "hip_gpuSpMM",
     "hip_gpuFlopsClassify", "hip_sgpuSpMM", "hip_csr_sort_rows", "spgemm_hip_selftest",
     "hip_spgemm_symbolic", "hip_spgemm_numeric", "hip_csr_row_flops", "spgemm_hip_kernel_name",
+    "hip_rmcl_prune", "hip_gpuRmclIter",
 ]
 
 
@@ -93,6 +94,10 @@ def lib():
                                         C.POINTER(C.c_longlong)]
         L.spgemm_hip_kernel_name.restype = C.c_char_p
         L.spgemm_hip_kernel_name.argtypes = [C.c_int]
+        L.hip_rmcl_prune.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + \
+            [C.POINTER(C.c_void_p)] * 3 + [_I]
+        L.hip_gpuRmclIter.argtypes = [C.c_int, C.c_int, C.c_int, _I, _I, _F, C.c_int, _I, _I, _F, C.c_int,
+                                      C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I]
         L.hip_csr_sort_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.spgemm_hip_selftest.argtypes = [C.c_void_p]
         L.free = C.CDLL(None).free
@@ -333,6 +338,25 @@ def scudaSpMM(hA, hB, handle=None):
         dA.deviceDispose()
         if dB is not dA:
             dB.deviceDispose()
+
+
+def gpuRmclIter(maxIter, Mgt, Mt):
+    """void gpuRmclIter(const int maxIter, const CSR Mgt, CSR& Mt): returns the new Mt (host CSR)."""
+    assert not Mgt.on_device and not Mt.on_device
+    L = lib()
+    oi, oj, ov, on = _I(), _I(), _F(), C.c_int(0)
+    rc = L.hip_gpuRmclIter(int(maxIter), Mgt.rows, Mgt.cols, Mgt.rowPtr.ctypes.data_as(_I), Mgt.colInd.ctypes.data_as(_I),
+                           Mgt.values.ctypes.data_as(_F), Mgt.nnz, Mt.rowPtr.ctypes.data_as(_I),
+                           Mt.colInd.ctypes.data_as(_I), Mt.values.ctypes.data_as(_F), Mt.nnz,
+                           C.byref(oi), C.byref(oj), C.byref(ov), C.byref(on))
+    _check(rc, "hip_gpuRmclIter")
+    n = on.value
+    rp = np.ctypeslib.as_array(oi, shape=(Mt.rows + 1,)).copy()
+    ci = np.ctypeslib.as_array(oj, shape=(n,)).copy() if n else np.zeros(0, np.int32)
+    v = np.ctypeslib.as_array(ov, shape=(n,)).copy() if n else np.zeros(0, np.float32)
+    for p in (oi, oj, ov):
+        L.free(C.cast(p, C.c_void_p))
+    return CSR(v, ci, rp, Mt.rows, Mt.cols, n)
 
 
 def sort_rows_device(dC, handle=None):

@@ -1,0 +1,88 @@
+// tests/cpp/testGpuSpMM.cc — the reference's own GPU test protocol (tests/testGpuSpMM.cc:9-46) against this
+// project's C++ mirror:  load -> toGpuCSR -> gpuSpMMWrapper -> toCpuCSR -> makeOrdered -> compare with the CPU
+// result.  The CPU result comes from the ORACLE (oracle/liboracle.so: test infrastructure, allowed here, never linked
+// into the product).  Also exercises hip_spmm (host in/out), scudaSpMM (classify + binned path) and, with
+// "--rmcl N", RMCL(file, N, GPU) vs the oracle's seqRmclIter restatement.
+//   usage: testGpuSpMM <file> [--rmcl N]        prints Same / Differs per check, exit code 0 iff all Same
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "COO.h"
+#include "CSR.h"
+#include "gpus/gpu_csr_kernel.h"
+#include "qrmcl.h"
+
+extern "C" {
+int oracle_sequential_spmm(const int*, const int*, const float*, int, const int*, const int*, const float*, int,
+                           int**, int**, float**, int*, int, int, int);
+int oracle_rmcl_iters(int, int, int, const int*, const int*, const float*, int, int**, int**, float**, int*);
+}
+
+static CSR oracle_spmm(const CSR& A, const CSR& B) {
+  int *IC, *JC, nnzC;
+  float* C;
+  oracle_sequential_spmm(A.rowPtr, A.colInd, A.values, A.nnz, B.rowPtr, B.colInd, B.values, B.nnz, &IC, &JC, &C, &nnzC,
+                         A.rows, A.cols, B.cols);
+  return CSR(C, JC, IC, A.rows, B.cols, nnzC);
+}
+
+static int report(const char* what, bool same) {
+  printf("%-28s %s\n", what, same ? "Same" : "Differs");
+  return same ? 0 : 1;
+}
+
+int main(int argc, char* argv[]) {
+  if (argc < 2) { printf("usage: %s <snap|mtx file> [--rmcl N]\n", argv[0]); return 2; }
+  int rmclIters = 0;
+  for (int i = 2; i + 1 < argc; ++i) if (!strcmp(argv[i], "--rmcl")) rmclIters = atoi(argv[i + 1]);
+  int bad = 0;
+  // mindex2-cuda/nGpuSpMM.cc:285-294: readSNAPFile(f,false) + dedupe + toCSR + toAbs, B = A
+  COO coo;
+  coo.readSNAPFile(argv[1], false);
+  coo.orderedAndDuplicatesRemoving();
+  CSR A = coo.toCSR();
+  A.toAbs();
+  coo.dispose();
+  CSR B = A.deepCopy();
+  CSR want = oracle_spmm(A, B);
+  want.makeOrdered();
+
+  CSR dA = A.toGpuCSR(), dB = B.toGpuCSR();
+  CSR dC = gpuSpMMWrapper(dA, dB);
+  dA.deviceDispose(); dB.deviceDispose();
+  CSR hC = dC.toCpuCSR();
+  dC.deviceDispose();
+  hC.makeOrdered();
+  bad += report("gpuSpMMWrapper isEqual", hC.isEqual(want));
+  bad += report("gpuSpMMWrapper parity", hC.isParityEqual(want));
+  hC.dispose();
+
+  CSR h2 = A.hip_spmm(B);
+  h2.makeOrdered();
+  bad += report("CSR::hip_spmm parity", h2.isParityEqual(want));
+  h2.dispose();
+
+  CSR h3 = scudaSpMM(A, B);
+  h3.makeOrdered();
+  bad += report("scudaSpMM parity", h3.isParityEqual(want));
+  h3.dispose();
+  printf("rows=%d nnzA=%d flops=%lld nnzC=%d\n", A.rows, A.nnz, A.spMMFlops(B), want.nnz);
+  want.dispose(); A.dispose(); B.dispose();
+
+  if (rmclIters > 0) {                            // nrmcl.cc:12-37 with GPU in the place of SOMP
+    CSR Mt = RMCL(argv[1], rmclIters, GPU);
+    COO c2;
+    c2.readSNAPFile(argv[1]);
+    CSR ref = rmclInit(c2);
+    c2.dispose();
+    CSR g = ref.deepCopy();
+    oracle_rmcl_iters(rmclIters, ref.rows, ref.cols, g.rowPtr, g.colInd, g.values, g.nnz, &ref.rowPtr, &ref.colInd,
+                      &ref.values, &ref.nnz);
+    Mt.makeOrdered();
+    ref.makeOrdered();
+    bad += report("RMCL(GPU) vs SEQ isEqual", Mt.isEqual(ref));
+    Mt.dispose(); ref.dispose(); g.dispose();
+  }
+  return bad ? 1 : 0;
+}
