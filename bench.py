@@ -169,8 +169,9 @@ def main():
             ab = algorithmic_bytes(kind, rows_, nza_, p_, nzc_)
             ach = ab / (avg[dom] * 1e-3) / 1e9
             traffic = None
-            if args.traffic_json and os.path.exists(args.traffic_json):
-                traffic = json.load(open(args.traffic_json)).get(dom)
+            tj = args.traffic_json or os.path.join(ROOT, "profiles", f"r01_{args.workload}_traffic.json")
+            if os.path.exists(tj):      # PMC-derived HBM bytes per launch, collected by profiles/collect.sh (separate passes)
+                traffic = json.load(open(tj)).get("kernels", {}).get(dom, {}).get("hbm_bytes_raw")
             roof = {"bound": "hbm", "kernel": dom, "avg_launch_ms": round(avg[dom], 4), "alg_bytes_per_launch": ab,
                     "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic,
