@@ -137,6 +137,25 @@ def omp_spmm(A, B, stride=512):
                    _take(cv, n, np.float32, L.oracle_free), A.rows, B.cols)
 
 
+def time_omp_spmm(A, B, use_ref, stride=512):
+    """Seconds spent inside the C call alone (no copy-out): the reference's omp_CSR_SpMM when use_ref, else the
+    restatement.  The malloc'd outputs are freed unread."""
+    import time
+    L = ref() if use_ref else lib()
+    free = L.ref_free if use_ref else L.oracle_free
+    ic, jc, cv, nnz = _I(), _I(), _F(), C.c_int()
+    args = [_ip(A.rowPtr), _ip(A.colInd), _fp(A.values), C.c_int(A.nnz), _ip(B.rowPtr), _ip(B.colInd), _fp(B.values),
+            C.c_int(B.nnz), C.byref(ic), C.byref(jc), C.byref(cv), C.byref(nnz), C.c_int(A.rows), C.c_int(A.cols),
+            C.c_int(B.cols), C.c_int(stride)]
+    t0 = time.perf_counter()
+    rc = L.ref_spmm(C.c_int(REF_KINDS["omp"]), *args) if use_ref else L.oracle_omp_spmm(*args)
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    for p_ in (ic, jc, cv):
+        free(C.cast(p_, C.c_void_p))
+    return dt, nnz.value
+
+
 REF_KINDS = {"sequential": 0, "omp": 1, "static_omp": 2, "flops_omp": 3, "group": 4, "noindex_somp": 5}
 
 

@@ -1,7 +1,7 @@
 """Diagnostic: run the stamps build of the library on one workload and print per-phase cycle shares."""
 import ctypes as C, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparse_matrix_with_flops_amd import hipspgemm as hs, synth
 hs.LIB_PATH = os.path.join(os.path.dirname(hs.LIB_PATH), "libspgemm_hip_stamps.so")
 wl = sys.argv[1] if len(sys.argv) > 1 else "256k"
