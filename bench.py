@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--workload", default="synth_1m_16", choices=sorted(WORKLOADS))
     ap.add_argument("--no-verify", action="store_true", help="skip the parity gate against the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="N>1: leave C row-sharded (no allgatherv inside the timed step)")
     ap.add_argument("--traffic-json", default=None, help="profiles/*.json with PMC-derived HBM bytes per kernel")
     args = ap.parse_args()
 
@@ -105,28 +107,35 @@ def main():
             torch.cuda.synchronize()
 
     out = None
+    gather = not args.no_gather
     for _ in range(args.warmup):
-        out = job.step()
+        out = job.step(gather)
     kern_ms = {}
     phase_ms = {"ms_classify": 0.0, "ms_symbolic": 0.0, "ms_scan_alloc": 0.0, "ms_numeric": 0.0, "ms_total": 0.0}
     barrier()
     t0 = time.perf_counter()
+    dev_ms = 0.0
     for _ in range(args.steps):
-        out = job.step()
-        st = engine.stats()                       # HIP-event durations of this step's launches (handle's stream)
+        out = job.step(gather)
+        st = engine.stats()
+        dev_ms += st["ms_total"]                       # HIP-event durations of this step's launches (handle's stream)
         for kname, ms in st["ms_kernel"].items():
             kern_ms[kname] = kern_ms.get(kname, 0.0) + ms
         for kk in phase_ms:
             phase_ms[kk] += st[kk]
     barrier()
     elapsed = time.perf_counter() - t0
+    nnz_local = int(out[1].numel())
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        tt = torch.tensor([elapsed, dev_ms, float(nnz_local)], dtype=torch.float64, device="cuda")
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        elapsed, dev_ms = float(mx[0].item()), float(mx[1].item())
+        nnz_sum = int(tt[2].item())
     ms_per_step = elapsed * 1e3 / args.steps
     rowPtrC, JC, CV = out
-    nnzC = int(JC.numel())
+    nnzC = nnz_local if (world == 1 or gather) else nnz_sum
     nnzA = int(rp[-1])
     bytes_alg = synth.bytes_alg(m, nnzA, P, nnzC)
     gflops = 2.0 * P / (ms_per_step * 1e-3) / 1e9
@@ -141,6 +150,11 @@ def main():
                    "parallelism": ("single GPU" if world == 1 else f"A row-sharded by flops over {world} GPUs, B replicated, "
                                    "allgatherv of C (send/recv pairs over xGMI)")},
         "output_nnz_per_s": round(nnzC / (ms_per_step * 1e-3), 1),
+        # device time of the SpGEMM phases alone (max over ranks, HIP events): what the step costs without the allgatherv
+        # of C.  The gather moves 8*nnzC bytes into every GPU; at xGMI link rates that exceeds the compute time at any N.
+        "compute_only": {"ms_per_step": round(dev_ms / args.steps, 4),
+                         "value": round(2.0 * P / (dev_ms / args.steps * 1e-3) / 1e9, 3), "unit": "GFLOP/s"},
+        "gather_in_step": bool(world > 1 and gather),
         "pipeline_bytes_alg_GBs": round(bytes_alg / (ms_per_step * 1e-3) / 1e9, 2),
         "pipeline_frac_of_hbm_peak": round(bytes_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world, 4),
     }
@@ -149,8 +163,8 @@ def main():
         # ---- roofline of the dominant kernel (rank 0's local rows; durations from HIP events in the timed region)
         flops_rows = engine.row_flops(job.A_local, job.B)
         rpl = job.A_local["rowPtr"].cpu().numpy().astype(np.int64)
-        cnt_rows = (rowPtrC.cpu().numpy().astype(np.int64)[job.r0 + 1:job.r1 + 1] -
-                    rowPtrC.cpu().numpy().astype(np.int64)[job.r0:job.r1]) if world > 1 else np.diff(rowPtrC.cpu().numpy().astype(np.int64))
+        rpc = rowPtrC.cpu().numpy().astype(np.int64)
+        cnt_rows = np.diff(rpc[job.r0:job.r1 + 1]) if (world > 1 and gather) else np.diff(rpc)
         b = bin_of(flops_rows)
         per_bin = {}
         for q in range(9):

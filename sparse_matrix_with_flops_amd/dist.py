@@ -127,10 +127,12 @@ class ShardedSpGEMM:
         del fullA
 
     # ---- one hot-path pass --------------------------------------------------------------------
-    def step(self):
+    def step(self, gather=True):
+        """gather=True: every rank returns the whole C (rowPtr, colInd, values).  gather=False: C stays row-sharded
+        like A — returns this rank's (local rowPtr, colInd, values) and no collective runs."""
         eng, G, me = self.engine, self.world, self.rank
         IC_loc, nnz_loc = eng.symbolic(self.A_local, self.B)
-        if G == 1:
+        if G == 1 or not gather:
             JC = eng.empty(max(nnz_loc, 1), torch.int32)
             Cv = eng.empty(max(nnz_loc, 1), torch.float32)
             eng.numeric(self.A_local, self.B, IC_loc, JC, Cv)
