@@ -637,23 +637,25 @@ __device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, in
     STAMP(8);
     const int T = st.incl[K - 1];
     const int nrounds = (T + WAVE - 1) / WAVE;
-    // boundaries between the 64-entry groups, wave-uniform, kept in registers: the top log2(NW) levels of the
-    // search are VALU compares against them instead of dependent LDS reads
-    int bnd[NW > 1 ? NW - 1 : 1];
-    if (NW > 1) {
-#pragma unroll
-      for (int i = 0; i < NW - 1; ++i) bnd[i] = __builtin_amdgcn_readfirstlane(st.incl[i * WAVE + WAVE - 1]);
-    }
+    // boundaries between the 64-entry groups: lane i holds the end of group i.  A round's 64 consecutive products
+    // almost always fall into one group, found with two ballots; the top log2(NW) search levels disappear
+    int bv = 0x7fffffff;
+    if (NW > 1 && lane < NW - 1) bv = st.incl[lane * WAVE + WAVE - 1];
     // ---- rounds: wave w owns rounds w, w+NW, ...; U of them per trip
     for (int r0 = w; r0 < nrounds; r0 += NW * U) {
       int p[U], e[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        p[u] = (r0 + u * NW) * WAVE + lane;
+        const int p0 = (r0 + u * NW) * WAVE;
+        p[u] = p0 + lane;
         int grp = 0;
         if (NW > 1) {
-#pragma unroll
-          for (int i = 0; i < NW - 1; ++i) grp += bnd[i] <= p[u] ? 1 : 0;
+          const int g0 = __popcll(__ballot(bv <= p0));
+          const int g1 = __popcll(__ballot(bv <= p0 + (WAVE - 1)));
+          grp = g0;
+          if (g0 != g1) {                            // the round straddles a group boundary (about 1 in 16)
+            for (int i = g0; i < g1; ++i) grp += st.incl[i * WAVE + WAVE - 1] <= p[u] ? 1 : 0;
+          }
         }
         e[u] = grp * WAVE;
       }
