@@ -946,6 +946,7 @@ constexpr int BIG_WPT = BIG_WORDS / BIG_THREADS;  // 8 words per thread
 constexpr int BIG_CAP = 18432;                 // float accumulators per rank pass (72 KB)
 constexpr int BH_SLOTS = 17408;                // hash kernel: 68 KB keys + 68 KB values (17 x 1024 slots, not a power of two)
 constexpr int BH_CAP = 12800;                  // distinct columns per hash pass (load <= 0.74 incl. partition skew)
+constexpr int BH_SPILL = 1 << 17;              // products a multi-pass row may park in HBM per block (1 MB of (col,val))
 
 struct BigSymShared {
   unsigned bitmap[SYM_WORDS];
@@ -969,6 +970,7 @@ struct BigHashShared {
   float vals[BH_SLOTS];
   RowStage<BIG_NW, BIG_U> st;
   int red[BIG_NW];
+  int spillCnt;
 };
 
 __device__ __forceinline__ int block_sum_16(int v, int* red) {
@@ -1148,7 +1150,14 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
   STAMP_FLUSH(0);
 }
 
-// numeric B (any n): multi-pass LDS hash
+// numeric B (any n): multi-pass LDS hash.  A row with more distinct columns than one table holds takes npass passes,
+// pass k owning the columns of hash class k.  Only pass 0 walks the products: what belongs to a later class is
+// parked as (col, a*b) pairs in a per-block HBM buffer and the later passes stream that buffer (coalesced, no
+// search, no gather).  Rows with more products than the buffer holds fall back to walking once per pass.
+__device__ __forceinline__ unsigned bh_class(int col, unsigned npass) {
+  return ((((unsigned)col * 0x85ebca6bu) >> 16) * npass) >> 16;     // second hash, independent of the slot hash
+}
+
 __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restrict__ binPtr, int bin,
                                                              const int* __restrict__ rowIds,
                                                              const int* __restrict__ IA, const int* __restrict__ JA,
@@ -1157,11 +1166,13 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
                                                              const float* __restrict__ VB,
                                                              const int* __restrict__ IC, int* __restrict__ JC,
                                                              float* __restrict__ C, int* __restrict__ err,
-                                                             int* __restrict__ qctr) {
+                                                             int* __restrict__ qctr, const int* __restrict__ rowFlops,
+                                                             int2* __restrict__ spill, int spillCap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   BigHashShared& sh = *reinterpret_cast<BigHashShared*>(smem_raw);
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
+  int2* const park = spill ? spill + (size_t)blockIdx.x * (size_t)spillCap : nullptr;
   for (int q = next_row(qctr, &sh.red[0]); q < count; q = next_row(qctr, &sh.red[0])) {
     const int row = rowIds[first + q];
     const int as = IA[row], ae = IA[row + 1];
@@ -1169,6 +1180,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
     const int outEnd = IC[row + 1];
     const int want = outEnd - outBase;
     const unsigned npass = (unsigned)((want + BH_CAP - 1) / BH_CAP);
+    const bool useSpill = npass > 1 && park != nullptr && rowFlops[row] <= spillCap;
     // any multiple of 1024 slots (64 per wave-step): twice the distinct columns of a pass when that fits
     const int perPass = (want + (int)npass - 1) / (int)npass;
     const int size = min(BH_SLOTS, max(BIG_THREADS, (2 * perPass + BIG_THREADS - 1) / BIG_THREADS * BIG_THREADS));
@@ -1176,18 +1188,56 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
     const int per = size / BIG_NW;
     for (unsigned pass = 0; pass < npass; ++pass) {
       for (int i = tid; i < size; i += BIG_THREADS) { sh.keys[i] = EMPTY_KEY; sh.vals[i] = 0.f; }
+      if (tid == 0 && pass == 0) sh.spillCnt = 0;
       __syncthreads();
-      for_each_product<BIG_NW, BIG_U, true>(sh.st, as, ae, JA, VA, IB, JB, VB,
-                                            [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&val)[BIG_U]) {
-        // hash class of a column: bits of a second multiplicative hash, independent of the slot hash
-        bool mine[BIG_U];
+      if (pass == 0 || !useSpill) {
+        for_each_product<BIG_NW, BIG_U, true>(sh.st, as, ae, JA, VA, IB, JB, VB,
+                                              [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&val)[BIG_U]) {
+          bool mine[BIG_U];
+          unsigned cls[BIG_U];
 #pragma unroll
-        for (int u = 0; u < BIG_U; ++u)
-          mine[u] = act[u] && (npass == 1 || (((unsigned)col[u] * 0x85ebca6bu) >> 12) % npass == pass);
-        hash_insert_multi<BIG_U, false>(sh.keys, sh.vals, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
-      });
+          for (int u = 0; u < BIG_U; ++u) {
+            cls[u] = npass == 1 ? 0u : bh_class(col[u], npass);
+            mine[u] = act[u] && cls[u] == pass;
+          }
+          hash_insert_multi<BIG_U, false>(sh.keys, sh.vals, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
+          if (useSpill) {                              // block-uniform; here pass == 0
+            unsigned long long mk[BIG_U];
+            int total = 0;
+#pragma unroll
+            for (int u = 0; u < BIG_U; ++u) { mk[u] = __ballot(act[u] && cls[u] != 0u); total += __popcll(mk[u]); }
+            if (total) {                               // wave-uniform
+              int base = 0;
+              if (lane == 0) base = atomicAdd(&sh.spillCnt, total);
+              base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+              for (int u = 0; u < BIG_U; ++u) {
+                if (act[u] && cls[u] != 0u) park[base + mask_rank(mk[u])] = make_int2(col[u], __float_as_int(val[u]));
+                base += __popcll(mk[u]);
+              }
+            }
+          }
+        });
+      } else {
+        const int cnt = sh.spillCnt;                  // written in pass 0, read-only since its closing barrier
+        for (int i0 = 0; i0 < cnt; i0 += BIG_THREADS * BIG_U) {
+          bool mine[BIG_U];
+          int col[BIG_U];
+          float val[BIG_U];
+#pragma unroll
+          for (int u = 0; u < BIG_U; ++u) {
+            const int idx = i0 + u * BIG_THREADS + tid;
+            const bool in = idx < cnt;
+            const int2 e = park[in ? idx : 0];
+            col[u] = e.x;
+            val[u] = __int_as_float(e.y);
+            mine[u] = in && bh_class(e.x, npass) == pass;
+          }
+          hash_insert_multi<BIG_U, false>(sh.keys, sh.vals, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
+        }
+        __syncthreads();
+      }
       // compaction: wave w sweeps slots [w*per, w*per+per), 64 per step -> coalesced stores
-      const int lane = lane_id(), w = tid >> 6;
       int mine = 0;
       for (int i = lane; i < per; i += WAVE) mine += sh.keys[w * per + i] != EMPTY_KEY;
       const int wtot = wave_sum(mine);

@@ -157,6 +157,8 @@ struct spgemm_handle {
   // the previous calls (the number of big rows is only known on the host after the symbolic phase).
   unsigned* bigBitmaps = nullptr;
   int bm_cap = 0;
+  int2* spill = nullptr;
+  int spill_blocks = 0;
   spgemm_stats stats;
 };
 
@@ -237,6 +239,7 @@ extern "C" int spgemm_hip_destroy(spgemm_handle* h) {
   for (auto& st : h->side) if (st && st != h->stream) { hipStreamSynchronize(st); hipStreamDestroy(st); }
   ws_free(h);
   hipFree(h->bigBitmaps);
+  hipFree(h->spill);
   hipFree(h->dsmall);
   hipHostFree(h->hsmall);
   for (auto& e : h->ev) if (e) hipEventDestroy(e);
@@ -416,8 +419,17 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const int* dJA, cons
                          bp, 8, rowIds, dIA, dJA, dA, dIB, dJB, dB, n, dIC, dJC, dC, err, h->bigBitmaps, h->bm_cap,
                          qc + 4);
     } else { KTimer t(h, SPGEMM_K_NUM_BIGHASH, st);
-      hipLaunchKernelGGL(k_num_bighash, dim3(clampi(rows(8, 9), 1, cu)), dim3(BIG_THREADS), sizeof(BigHashShared), st,
-                         bp, 8, rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 4); }
+      const int blocks = clampi(rows(8, 9), 1, cu);
+      if (blocks > h->spill_blocks) {                  // parking space of multi-pass rows: 1 MB per block, kept
+        hipFree(h->spill);
+        h->spill = nullptr;
+        h->spill_blocks = 0;
+        if (hipMalloc((void**)&h->spill, (size_t)blocks * BH_SPILL * sizeof(int2)) == hipSuccess) h->spill_blocks = blocks;
+        else (void)hipGetLastError();                  // without it those rows walk once per pass
+      }
+      hipLaunchKernelGGL(k_num_bighash, dim3(blocks), dim3(BIG_THREADS), sizeof(BigHashShared), st,
+                         bp, 8, rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 4, h->rowFlops,
+                         h->spill_blocks >= blocks ? h->spill : (int2*)nullptr, BH_SPILL); }
   }
   if (rows(7, 8) > 0) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_NUM_HASH8, st);
     LAUNCH_U(k_num_hash, 8, 8192, dim3(clampi(rows(7, 8), 1, cu * 2)), dim3(512), st, bp, 7,
