@@ -597,6 +597,7 @@ struct RowStage {
   int off[WAVE * NW];      // IB[j] - exclusive scan: product p of the chunk lives at JB[off + p]
   float aval[WAVE * NW];
   int wsum[NW];
+  int trip;                // next unclaimed trip of the staged chunk (NW > 1: waves claim trips as they finish)
   int dummy[WAVE * NW];    // one private word per lane: target of predicated-off atomics
 };
 
@@ -633,6 +634,7 @@ __device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, in
     st.incl[tid] = incl;
     st.off[tid] = bs - (incl - len);
     if (NEED_VAL) st.aval[tid] = a;
+    if (NW > 1 && tid == 0) st.trip = NW;
     __syncthreads();
     STAMP(8);
     const int T = st.incl[K - 1];
@@ -641,12 +643,16 @@ __device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, in
     // almost always fall into one group, found with two ballots; the top log2(NW) search levels disappear
     int bv = 0x7fffffff;
     if (NW > 1 && lane < NW - 1) bv = st.incl[lane * WAVE + WAVE - 1];
-    // ---- rounds: wave w owns rounds w, w+NW, ...; U of them per trip
-    for (int r0 = w; r0 < nrounds; r0 += NW * U) {
+    // ---- trips of U consecutive rounds (64*U products).  The first NW trips are dealt out, the rest are claimed
+    // from an LDS counter as waves finish: probe chains make trip times uneven and the chunk ends on a barrier
+    const int ntrips = (nrounds + U - 1) / U;
+    for (int t = w; t < ntrips;) {
+      int tnext = t + 1;
+      if (NW > 1) { tnext = 0; if (lane == 0) tnext = atomicAdd(&st.trip, 1); }
       int p[U], e[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int p0 = (r0 + u * NW) * WAVE;
+        const int p0 = (t * U + u) * WAVE;
         p[u] = p0 + lane;
         int grp = 0;
         if (NW > 1) {
@@ -692,6 +698,7 @@ __device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, in
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       STAMP(9);                                   // insert done
 #endif
+      t = NW > 1 ? __builtin_amdgcn_readfirstlane(tnext) : tnext;
     }
     STAMP(7);
     __syncthreads();
@@ -945,8 +952,11 @@ constexpr int BIG_WORDS = BIG_WC / 32;         // 8192
 constexpr int BIG_WPT = BIG_WORDS / BIG_THREADS;  // 8 words per thread
 constexpr int BIG_CAP = 18432;                 // float accumulators per rank pass (72 KB)
 constexpr int BH_SLOTS = 17408;                // hash kernel: 68 KB keys + 68 KB values (17 x 1024 slots, not a power of two)
-constexpr int BH_CAP = 12800;                  // distinct columns per hash pass (load <= 0.74 incl. partition skew)
-constexpr int BH_SPILL = 1 << 17;              // products a multi-pass row may park in HBM per block (1 MB of (col,val))
+constexpr int BH_CAP = 10240;                  // distinct columns per hash pass (load <= 0.6 incl. partition skew; measured
+                                               // best of 8704/10240/12800 once later passes stream parked products)
+constexpr int BH_CAP_MAX = 12800;              // SPGEMM_BHCAP may raise the cap to this (load 0.74)
+constexpr int BH_SPILL = 1 << 18;              // (col,val) pairs a multi-pass row may park in HBM per block (2 MB)
+constexpr int BH_MAXCLS = 16;                  // hash classes (passes) with their own parking region
 
 struct BigSymShared {
   unsigned bitmap[SYM_WORDS];
@@ -970,7 +980,7 @@ struct BigHashShared {
   float vals[BH_SLOTS];
   RowStage<BIG_NW, BIG_U> st;
   int red[BIG_NW];
-  int spillCnt;
+  int spillCnt[BH_MAXCLS];
 };
 
 __device__ __forceinline__ int block_sum_16(int v, int* red) {
@@ -1167,20 +1177,25 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
                                                              const int* __restrict__ IC, int* __restrict__ JC,
                                                              float* __restrict__ C, int* __restrict__ err,
                                                              int* __restrict__ qctr, const int* __restrict__ rowFlops,
-                                                             int2* __restrict__ spill, int spillCap) {
+                                                             int2* __restrict__ spill, int spillCap, int bhCap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   BigHashShared& sh = *reinterpret_cast<BigHashShared*>(smem_raw);
   const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
   int2* const park = spill ? spill + (size_t)blockIdx.x * (size_t)spillCap : nullptr;
+  STAMP_DECL;
   for (int q = next_row(qctr, &sh.red[0]); q < count; q = next_row(qctr, &sh.red[0])) {
+    STAMP(0);
     const int row = rowIds[first + q];
     const int as = IA[row], ae = IA[row + 1];
     int outBase = IC[row];
     const int outEnd = IC[row + 1];
     const int want = outEnd - outBase;
-    const unsigned npass = (unsigned)((want + BH_CAP - 1) / BH_CAP);
-    const bool useSpill = npass > 1 && park != nullptr && rowFlops[row] <= spillCap;
+    const unsigned npass = (unsigned)((want + bhCap - 1) / bhCap);
+    // class c >= 1 parks in its own region of `stride` pairs (no class can hold more than the row's products)
+    const int stride = rowFlops[row];
+    const bool useSpill = npass > 1 && npass <= (unsigned)BH_MAXCLS && park != nullptr &&
+                          (long long)(npass - 1) * stride <= (long long)spillCap;
     // any multiple of 1024 slots (64 per wave-step): twice the distinct columns of a pass when that fits
     const int perPass = (want + (int)npass - 1) / (int)npass;
     const int size = min(BH_SLOTS, max(BIG_THREADS, (2 * perPass + BIG_THREADS - 1) / BIG_THREADS * BIG_THREADS));
@@ -1188,8 +1203,9 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
     const int per = size / BIG_NW;
     for (unsigned pass = 0; pass < npass; ++pass) {
       for (int i = tid; i < size; i += BIG_THREADS) { sh.keys[i] = EMPTY_KEY; sh.vals[i] = 0.f; }
-      if (tid == 0 && pass == 0) sh.spillCnt = 0;
+      if (pass == 0 && tid < BH_MAXCLS) sh.spillCnt[tid] = 0;
       __syncthreads();
+      STAMP(1);
       if (pass == 0 || !useSpill) {
         for_each_product<BIG_NW, BIG_U, true>(sh.st, as, ae, JA, VA, IB, JB, VB,
                                               [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&val)[BIG_U]) {
@@ -1202,40 +1218,52 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
           }
           hash_insert_multi<BIG_U, false>(sh.keys, sh.vals, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
           if (useSpill) {                              // block-uniform; here pass == 0
-            unsigned long long mk[BIG_U];
-            int total = 0;
+            for (unsigned c = 1; c < npass; ++c) {
+              unsigned long long mk[BIG_U];
+              int total = 0;
 #pragma unroll
-            for (int u = 0; u < BIG_U; ++u) { mk[u] = __ballot(act[u] && cls[u] != 0u); total += __popcll(mk[u]); }
-            if (total) {                               // wave-uniform
-              int base = 0;
-              if (lane == 0) base = atomicAdd(&sh.spillCnt, total);
-              base = __builtin_amdgcn_readfirstlane(base);
+              for (int u = 0; u < BIG_U; ++u) { mk[u] = __ballot(act[u] && cls[u] == c); total += __popcll(mk[u]); }
+              if (total) {                             // wave-uniform
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&sh.spillCnt[c], total);
+                base = __builtin_amdgcn_readfirstlane(base);
+                int2* const dst = park + (size_t)(c - 1) * (size_t)stride;
 #pragma unroll
-              for (int u = 0; u < BIG_U; ++u) {
-                if (act[u] && cls[u] != 0u) park[base + mask_rank(mk[u])] = make_int2(col[u], __float_as_int(val[u]));
-                base += __popcll(mk[u]);
+                for (int u = 0; u < BIG_U; ++u) {
+                  if (act[u] && cls[u] == c) dst[base + mask_rank(mk[u])] = make_int2(col[u], __float_as_int(val[u]));
+                  base += __popcll(mk[u]);
+                }
               }
             }
           }
-        });
+        } STAMP_ARGS);
+        STAMP(2);
       } else {
-        const int cnt = sh.spillCnt;                  // written in pass 0, read-only since its closing barrier
+        // stream this class's parked pairs; the next batch is in flight while the current one is inserted
+        const int cnt = sh.spillCnt[pass];            // written in pass 0, read-only since its closing barrier
+        const int2* const src = park + (size_t)(pass - 1) * (size_t)stride;
+        int2 nxt[BIG_U];
+#pragma unroll
+        for (int u = 0; u < BIG_U; ++u) { const int idx = u * BIG_THREADS + tid; nxt[u] = src[idx < cnt ? idx : 0]; }
         for (int i0 = 0; i0 < cnt; i0 += BIG_THREADS * BIG_U) {
           bool mine[BIG_U];
           int col[BIG_U];
           float val[BIG_U];
 #pragma unroll
           for (int u = 0; u < BIG_U; ++u) {
-            const int idx = i0 + u * BIG_THREADS + tid;
-            const bool in = idx < cnt;
-            const int2 e = park[in ? idx : 0];
-            col[u] = e.x;
-            val[u] = __int_as_float(e.y);
-            mine[u] = in && bh_class(e.x, npass) == pass;
+            col[u] = nxt[u].x;
+            val[u] = __int_as_float(nxt[u].y);
+            mine[u] = i0 + u * BIG_THREADS + tid < cnt;
+          }
+#pragma unroll
+          for (int u = 0; u < BIG_U; ++u) {
+            const int idx = i0 + BIG_THREADS * BIG_U + u * BIG_THREADS + tid;
+            nxt[u] = src[idx < cnt ? idx : 0];
           }
           hash_insert_multi<BIG_U, false>(sh.keys, sh.vals, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
         }
         __syncthreads();
+        STAMP(3);
       }
       // compaction: wave w sweeps slots [w*per, w*per+per), 64 per step -> coalesced stores
       int mine = 0;
@@ -1254,10 +1282,13 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
       }
       outBase += total;
       __syncthreads();
+      STAMP(4);
     }
     if (tid == 0 && outBase != outEnd) atomicOr(err, ERRF_COUNT_MISMATCH);
     __syncthreads();
   }
+  STAMP(0);
+  STAMP_FLUSH(0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ hs.lib().spgemm_hip_debug_stamps(buf, 1)
 dC = hs.gpuSpMMWrapper(A, A, h); dC.deviceDispose()
 hs.lib().spgemm_hip_debug_stamps(buf, 0)
 a = np.array(buf[:], dtype=np.float64).reshape(4, 16)
-names = {0: ("k_num_big", ["next_row+meta", "bitmap", "prefix", "JC store+sync", "clear acc", "products-rest", "store C", "emit sync-wait", "w:stage", "w:rounds", "w:endsync", "emit bitloops"]),
+names = {0: ("k_num_bighash", ["next_row+meta", "clear", "walk-rest", "spill stream", "compact", "r:search", "r:gather", "r:looptail", "w:stage", "r:insert(+park)", "w:endsync"]) if m > 262144 else ("k_num_big", ["next_row+meta", "bitmap", "prefix", "JC store+sync", "clear acc", "products-rest", "store C", "emit sync-wait", "w:stage", "w:rounds", "w:endsync", "emit bitloops"]),
          1: ("k_num_hash<1>", ["loop", "meta", "clear", "products-rest", "compact", "r:search", "r:gather", "r:looptail", "w:stage", "r:insert", "w:endsync"]),
          2: ("k_num_hash<4>", ["loop", "next_row+meta", "clear", "products-rest", "compact", "r:search", "r:gather", "r:looptail", "w:stage", "r:insert", "w:endsync"]),
          3: ("k_num_hash<8>", ["loop", "next_row+meta", "clear", "products-rest", "compact", "r:search", "r:gather", "r:looptail", "w:stage", "r:insert", "w:endsync"])}
