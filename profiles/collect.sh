@@ -10,4 +10,5 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.log 2>&1; echo "fetch exit=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.log 2>&1; echo "write exit=$?"
 cd - > /dev/null
-python3 profiles/summarize.py $OUT $TAG $WL
+python3 profiles/summarize.py $OUT $TAG $WL   # on the box (bench.py reads the traffic file); re-run it locally after the merge,
+# only gpurun_out/ travels back

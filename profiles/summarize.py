@@ -32,6 +32,7 @@ def short(name):
 
 def counter_avg(sub, counter):
     files = glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True)
+    files = sorted(files, key=os.path.getmtime)[-1:]      # gpurun merges runs into one directory: newest only
     tot, n = collections.defaultdict(float), collections.defaultdict(set)
     for f in files:
         for r in csv.DictReader(open(f)):
@@ -44,9 +45,9 @@ def counter_avg(sub, counter):
     return {k: tot[k] / max(len(n[k]), 1) for k in tot}
 
 
-stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
+stats = sorted(glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 if stats:
-    shutil.copy(stats[0], os.path.join(here, f"{tag}_{wl}_kernel_stats.csv"))
+    shutil.copy(stats[-1], os.path.join(here, f"{tag}_{wl}_kernel_stats.csv"))
 fetch, write = counter_avg("fetch", "FETCH_SIZE"), counter_avg("write", "WRITE_SIZE")
 traffic = {}
 for k in sorted(set(fetch) | set(write)):
