@@ -76,6 +76,7 @@ int  spgemm_hip_malloc(void** dptr, size_t bytes);
 int  spgemm_hip_free(void* dptr);
 int  spgemm_hip_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int  spgemm_hip_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int  spgemm_hip_memcpy_d2d(void* dst, const void* src, size_t bytes);   /* device to device, same GPU */
 
 /* ---- (1) host arrays in, host arrays out ------------------------------------------------------
  * Replaces the *_CSR_SpMM family:  sequential_CSR_SpMM / omp_CSR_SpMM / static_omp_CSR_SpMM /

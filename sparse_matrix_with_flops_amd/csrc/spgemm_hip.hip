@@ -291,6 +291,12 @@ extern "C" int spgemm_hip_memcpy_d2h(void* dst, const void* src, size_t bytes) {
   return SPGEMM_OK;
 }
 
+extern "C" int spgemm_hip_memcpy_d2d(void* dst, const void* src, size_t bytes) {
+  if (bytes && (!dst || !src)) return fail(SPGEMM_ERR_ARG, "null pointer in d2d copy");
+  if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+  return SPGEMM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // launch sequence
 // ------------------------------------------------------------------------------------------------

@@ -86,6 +86,30 @@ class HipEngine:
                               _ptr(B["rowPtr"]), _ptr(B["colInd"]), _ptr(B["values"]), B["nnz"], A["rows"], A["cols"],
                               B["cols"], _ptr(IC), _ptr(JC_out), _ptr(C_out))
 
+    def expand_prune(self, A, B):
+        """One R-MCL step on this rank's rows: C = A*B (hip_gpuSpMM), then inflate/prune/normalise + compaction
+        (hip_rmcl_prune), all on the device.  Returns torch tensors (rowPtr[rows+1], colInd, values)."""
+        self.sync()
+        ic, jc, cv, _ = hs.gpu_spmm_raw(self.handle, _ptr(A["rowPtr"]), _ptr(A["colInd"]), _ptr(A["values"]), A["nnz"],
+                                        _ptr(B["rowPtr"]), _ptr(B["colInd"]), _ptr(B["values"]), B["nnz"],
+                                        A["rows"], A["cols"], B["cols"])
+        try:
+            pi, pj, pv, nn = hs.rmcl_prune_raw(self.handle, A["rows"], ic, jc, cv)
+        finally:
+            for p in (ic, jc, cv):
+                hs.dev_free(p)
+        try:
+            rp = self.empty(A["rows"] + 1, torch.int32)
+            ci = self.empty(max(nn, 1), torch.int32)
+            v = self.empty(max(nn, 1), torch.float32)
+            hs.d2d(rp.data_ptr(), pi, 4 * (A["rows"] + 1))
+            hs.d2d(ci.data_ptr(), pj, 4 * nn)
+            hs.d2d(v.data_ptr(), pv, 4 * nn)
+        finally:
+            for p in (pi, pj, pv):
+                hs.dev_free(p)
+        return rp, ci[:nn], v[:nn]
+
     def stats(self):
         return self.handle.stats()
 
@@ -138,15 +162,8 @@ class ShardedSpGEMM:
             eng.numeric(self.A_local, self.B, IC_loc, JC, Cv)
             return IC_loc, JC[:nnz_loc], Cv[:nnz_loc]
         # (1) segment sizes
-        mine = torch.tensor([nnz_loc], dtype=torch.int64, device=IC_loc.device)
-        sizes = [torch.zeros(1, dtype=torch.int64, device=IC_loc.device) for _ in range(G)]
-        dist.all_gather(sizes, mine, group=self.group)
-        counts = [int(s.item()) for s in sizes]
-        offs = np.zeros(G + 1, dtype=np.int64)
-        np.cumsum(counts, out=offs[1:])
+        offs = _segment_offsets(self.group, G, nnz_loc, IC_loc.device)
         total = int(offs[G])
-        if total > 0x7fffffff:
-            raise hs.SpgemmError(f"nnz(C)={total} does not fit the int32 CSR of the boundary")
         # (2) numeric straight into this rank's slice of the gathered arrays
         rowPtr = eng.empty(self.m + 1, torch.int32)
         JC = eng.empty(max(total, 1), torch.int32)
@@ -157,24 +174,106 @@ class ShardedSpGEMM:
         if me == G - 1:
             rowPtr[self.m] = total
         # (3) allgatherv of the three arrays: pairwise send/recv, one link per peer
-        ops = []
-        for r in range(G):
-            if r == me:
-                continue
-            a0, a1 = int(offs[r]), int(offs[r + 1])
-            rr0, rr1 = int(self.ends[r]), int(self.ends[r + 1]) + (1 if r == G - 1 else 0)
-            my_rows_hi = self.r1 + (1 if me == G - 1 else 0)
-            if my_rows_hi > self.r0:
-                ops.append(dist.P2POp(dist.isend, rowPtr[self.r0:my_rows_hi], r, self.group))
-            if rr1 > rr0:
-                ops.append(dist.P2POp(dist.irecv, rowPtr[rr0:rr1], r, self.group))
-            if o1 > o0:
-                ops.append(dist.P2POp(dist.isend, JC[o0:o1], r, self.group))
-                ops.append(dist.P2POp(dist.isend, Cv[o0:o1], r, self.group))
-            if a1 > a0:
-                ops.append(dist.P2POp(dist.irecv, JC[a0:a1], r, self.group))
-                ops.append(dist.P2POp(dist.irecv, Cv[a0:a1], r, self.group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        _allgatherv_csr(self.group, me, G, self.ends, self.m, offs, rowPtr, JC, Cv)
         return rowPtr, JC[:total], Cv[:total]
+
+
+def _allgatherv_csr(group, me, G, ends, m, offs, rowPtr, JC, Cv):
+    """Every rank has filled its own rows of rowPtr (global offsets; the last rank also rowPtr[m]) and its own
+    segment [offs[me], offs[me+1]) of JC/Cv; exchange so that all ranks hold everything.  Grouped isend/irecv pairs:
+    each peer's segment travels its own xGMI link."""
+    r0, r1 = int(ends[me]), int(ends[me + 1])
+    o0, o1 = int(offs[me]), int(offs[me + 1])
+    my_rows_hi = r1 + (1 if me == G - 1 else 0)
+    ops = []
+    for r in range(G):
+        if r == me:
+            continue
+        a0, a1 = int(offs[r]), int(offs[r + 1])
+        rr0, rr1 = int(ends[r]), int(ends[r + 1]) + (1 if r == G - 1 else 0)
+        if my_rows_hi > r0:
+            ops.append(dist.P2POp(dist.isend, rowPtr[r0:my_rows_hi], r, group))
+        if rr1 > rr0:
+            ops.append(dist.P2POp(dist.irecv, rowPtr[rr0:rr1], r, group))
+        if o1 > o0:
+            ops.append(dist.P2POp(dist.isend, JC[o0:o1], r, group))
+            ops.append(dist.P2POp(dist.isend, Cv[o0:o1], r, group))
+        if a1 > a0:
+            ops.append(dist.P2POp(dist.irecv, JC[a0:a1], r, group))
+            ops.append(dist.P2POp(dist.irecv, Cv[a0:a1], r, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+def _segment_offsets(group, G, nnz_loc, device):
+    """all-gather of the per-rank segment sizes -> offs[G+1] (int64 numpy)"""
+    mine = torch.tensor([nnz_loc], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(G)]
+    dist.all_gather(sizes, mine, group=group)
+    offs = np.zeros(G + 1, dtype=np.int64)
+    np.cumsum([int(x.item()) for x in sizes], out=offs[1:])
+    if int(offs[G]) > 0x7fffffff:
+        raise hs.SpgemmError(f"nnz={int(offs[G])} does not fit the int32 CSR of the boundary")
+    return offs
+
+
+class ShardedRMCL:
+    """R-MCL over the process group (BASELINE configs[4]): Mt <- prune(Mgt * Mt), maxIter times
+    (nlibs/qrmcl.cc:86-124; the reference's GPU loop is single-device, nlibs/gpus/gpu_csr_kernel.cu:281-311).
+    Mgt's row blocks (cut once, by the flops of the first expansion) stay resident per GPU; Mt is replicated.
+    Inflate/prune/normalise are row-local, so they run BEFORE the gather: what crosses xGMI is the pruned block,
+    several times smaller than the raw product."""
+
+    def __init__(self, engine, Mgt_host, Mt_host, group=None):
+        """Mgt_host/Mt_host: (rowPtr, colInd, values, rows, cols) numpy tuples, identical on every rank."""
+        self.engine = engine
+        self.group = group
+        on = bool(dist and dist.is_initialized())
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        rpG, ciG, vG, mG, kG = Mgt_host
+        self.m, self.k = int(mG), int(kG)
+        self.Mt = make_matrix(engine, *Mt_host)
+        fullG = make_matrix(engine, *Mgt_host)
+        flops = engine.row_flops(fullG, self.Mt)
+        del fullG
+        prefix = np.zeros(self.m + 1, dtype=np.int64)
+        np.cumsum(flops, out=prefix[1:])
+        self.ends = equal_partition64(prefix, self.world)
+        self.r0, self.r1 = int(self.ends[self.rank]), int(self.ends[self.rank + 1])
+        rpG = np.asarray(rpG)
+        lo, hi = int(rpG[self.r0]), int(rpG[self.r1])
+        self.Mgt_local = make_matrix(engine, (rpG[self.r0:self.r1 + 1] - lo).astype(np.int32), np.asarray(ciG)[lo:hi],
+                                     np.asarray(vG)[lo:hi], self.r1 - self.r0, self.k)
+
+    def iterate(self, maxIter):
+        """Runs maxIter steps; returns the replicated Mt as a dict of device tensors (rowPtr, colInd, values, ...)."""
+        eng, G, me = self.engine, self.world, self.rank
+        for _ in range(int(maxIter)):
+            rp_loc, ci_loc, v_loc = eng.expand_prune(self.Mgt_local, self.Mt)
+            nn = int(ci_loc.numel())
+            if G == 1:
+                rowPtr, JC, Cv, total = rp_loc, ci_loc, v_loc, nn
+            else:
+                offs = _segment_offsets(self.group, G, nn, rp_loc.device)
+                total = int(offs[G])
+                o0 = int(offs[me])
+                rowPtr = eng.empty(self.m + 1, torch.int32)
+                JC = eng.empty(max(total, 1), torch.int32)
+                Cv = eng.empty(max(total, 1), torch.float32)
+                rowPtr[self.r0:self.r1] = rp_loc[:-1] + o0
+                if me == G - 1:
+                    rowPtr[self.m] = total
+                if nn:
+                    JC[o0:o0 + nn] = ci_loc
+                    Cv[o0:o0 + nn] = v_loc
+                _allgatherv_csr(self.group, me, G, self.ends, self.m, offs, rowPtr, JC, Cv)
+                JC, Cv = JC[:total], Cv[:total]
+            self.Mt = {"rowPtr": rowPtr, "colInd": JC, "values": Cv, "rows": self.m, "cols": self.Mt["cols"],
+                       "nnz": total}
+        return self.Mt
+
+    def result_host(self):
+        M = self.Mt
+        return (M["rowPtr"].cpu().numpy(), M["colInd"][:M["nnz"]].cpu().numpy(), M["values"][:M["nnz"]].cpu().numpy())

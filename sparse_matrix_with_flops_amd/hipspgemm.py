@@ -30,7 +30,7 @@ _F = C.POINTER(C.c_float)
 EXPORTS = [
     "spgemm_hip_last_error", "spgemm_hip_device_count", "spgemm_hip_create", "spgemm_hip_destroy",
     "spgemm_hip_get_stats", "spgemm_hip_stream", "spgemm_hip_malloc", "spgemm_hip_free",
-    "spgemm_hip_memcpy_h2d", "spgemm_hip_memcpy_d2h", "hip_CSR_SpMM", "hip_gpuSpMM",
+    "spgemm_hip_memcpy_h2d", "spgemm_hip_memcpy_d2h", "spgemm_hip_memcpy_d2d", "hip_CSR_SpMM", "hip_gpuSpMM",
     "hip_gpuFlopsClassify", "hip_sgpuSpMM", "hip_csr_sort_rows", "spgemm_hip_selftest",
     "hip_spgemm_symbolic", "hip_spgemm_numeric", "hip_csr_row_flops", "spgemm_hip_kernel_name",
     "hip_rmcl_prune", "hip_gpuRmclIter",
@@ -94,6 +94,7 @@ def lib():
                                         C.POINTER(C.c_longlong)]
         L.spgemm_hip_kernel_name.restype = C.c_char_p
         L.spgemm_hip_kernel_name.argtypes = [C.c_int]
+        L.spgemm_hip_memcpy_d2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.hip_rmcl_prune.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + \
             [C.POINTER(C.c_void_p)] * 3 + [_I]
         L.hip_gpuRmclIter.argtypes = [C.c_int, C.c_int, C.c_int, _I, _I, _F, C.c_int, _I, _I, _F, C.c_int,
@@ -286,6 +287,20 @@ def spgemm_numeric_raw(handle, IA, JA, VA, nnzA, IB, JB, VB, nnzB, m, k, n, IC, 
     _check(lib().hip_spgemm_numeric(handle.ptr, C.c_void_p(IA), C.c_void_p(JA), C.c_void_p(VA), int(nnzA),
                                     C.c_void_p(IB), C.c_void_p(JB), C.c_void_p(VB), int(nnzB), int(m), int(k), int(n),
                                     C.c_void_p(IC), C.c_void_p(JC_out), C.c_void_p(C_out)), "hip_spgemm_numeric")
+
+
+def d2d(dst, src, nbytes):
+    """Device-to-device copy between raw pointers (library pool <-> memory owned elsewhere)."""
+    _check(lib().spgemm_hip_memcpy_d2d(C.c_void_p(dst), C.c_void_p(src), int(nbytes)), "spgemm_hip_memcpy_d2d")
+
+
+def rmcl_prune_raw(handle, m, IC, JC, CV):
+    """hip_rmcl_prune on raw device pointers: inflate/prune/normalise the rows of C, compacted into new pool arrays.
+    Returns (IN, JN, CN, nnzN); release the three with dev_free."""
+    i_, j_, c_, n_ = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+    _check(lib().hip_rmcl_prune(handle.ptr if handle else None, int(m), C.c_void_p(IC), C.c_void_p(JC), C.c_void_p(CV),
+                                C.byref(i_), C.byref(j_), C.byref(c_), C.byref(n_)), "hip_rmcl_prune")
+    return i_.value, j_.value, c_.value, n_.value
 
 
 def row_flops_raw(handle, IA, JA, IB, m, out_ptr):

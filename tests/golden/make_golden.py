@@ -75,7 +75,7 @@ def main():
         pack(f"rect{idx}_C", po.ref_spmm(A, B, "sequential"), sm)
     np.savez_compressed(os.path.join(HERE, "synth_small.npz"), **sm)
 
-    for (m, seed, base) in [(4096, 11, 2), (32768, 13, 2), (65536, 17, 4), (262144, 42, 2)]:
+    for (m, seed, base) in [(4096, 11, 2), (32768, 13, 2), (65536, 17, 4), (262144, 42, 2), (1048576, 43, 2)]:
         A = synth_csr(m, seed, base)
         Cm = po.ref_spmm(A, A, "omp")
         pref = po.ref_row_flops_prefix(A, A)

@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from helpers import assert_parity, po, synth_csr
-from sparse_matrix_with_flops_amd.dist import ShardedSpGEMM, equal_partition64
+from sparse_matrix_with_flops_amd.dist import ShardedRMCL, ShardedSpGEMM, equal_partition64
 
 
 class OracleEngine:
@@ -41,6 +41,10 @@ class OracleEngine:
     def numeric(self, A, B, IC, JC_out, C_out):
         JC_out.copy_(torch.from_numpy(self._C.colInd))
         C_out.copy_(torch.from_numpy(self._C.values))
+
+    def expand_prune(self, A, B):
+        R = po.rmcl_iters(self._host(A), self._host(B), 1)               # prune(A*B), rows of A
+        return (torch.from_numpy(R.rowPtr.copy()), torch.from_numpy(R.colInd.copy()), torch.from_numpy(R.values.copy()))
 
 
 def _free_port():
@@ -86,6 +90,49 @@ def test_sharded_spgemm_gloo(world):
     # balanced: no rank has more than ~1/world + one heavy row of the work
     shares = [o[5] for o in sorted(outs)]
     assert sum(shares) == int(flops.sum()) and max(shares) <= flops.sum() / world + flops.max()
+
+
+def _rmcl_graph(m, seed):
+    A = synth_csr(m, seed, 2)
+    ri = np.repeat(np.arange(A.rows, dtype=np.int32), np.diff(A.rowPtr))
+    return po.rmcl_init(A.rows, A.cols, A.colInd, ri, np.ones_like(A.values))     # transpose + self loops + 1/deg
+
+
+def _rmcl_worker(rank, world, port, m, seed, iters, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Mt = _rmcl_graph(m, seed)
+        host = (Mt.rowPtr, Mt.colInd, Mt.values, Mt.rows, Mt.cols)
+        job = ShardedRMCL(OracleEngine(), host, host)
+        job.iterate(iters)
+        rp, ci, v = job.result_host()
+        q.put((rank, rp.copy(), ci.copy(), v.copy(), job.ends.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_rmcl_gloo(world):
+    """R-MCL with Mgt row-sharded and the pruned blocks gathered every iteration == the sequential loop, bit for bit
+    (the local engine here is the sequential oracle, so even the float bits agree)."""
+    m, seed, iters = 1500, 23, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rmcl_worker, args=(r, world, port, m, seed, iters, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    Mt = _rmcl_graph(m, seed)
+    want = po.rmcl_iters(Mt, Mt, iters)
+    for rank, rp, ci, v, ends in outs:
+        assert ends[0] == 0 and ends[-1] == m and np.all(np.diff(ends) > 0)
+        assert np.array_equal(rp, want.rowPtr) and np.array_equal(ci, want.colInd), f"rank {rank}"
+        assert np.array_equal(v.view(np.uint32), want.values.view(np.uint32)), f"rank {rank}"
 
 
 def test_partition_matches_reference_rule():

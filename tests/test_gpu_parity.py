@@ -112,6 +112,24 @@ def test_headline_config_device_resident(handle):
     assert s["hash"] == g["hash"] and abs(s["sum"] - g["sum"]) <= 1e-6 * abs(g["sum"])
 
 
+def test_bench_workload_1m_rows_vs_reference_summary(handle):
+    """bench.py's default workload (1 048 576 rows, seed 43; columns exceed the 262 144-column rank kernel, so rows
+    above 4096 products take the LDS hash kernel incl. multi-pass rows that park products in HBM) against the summary
+    the real reference produced for it: nnz, structure hash (bit-exact), value checksums (1e-6)."""
+    g = META["synth"]["1048576_43_2"]
+    A = synth_csr(g["m"], g["seed"], g["base"])
+    dA = to_hs(A).toGpuCSR()
+    dC = hs.gpuSpMMWrapper(dA, dA, handle)
+    st = handle.stats()
+    assert st["total_flops"] == g["P"] and st["nnzC"] == g["nnz"]
+    got = dC.toCpuCSR()
+    dC.deviceDispose()
+    dA.deviceDispose()
+    s = summarize(got)
+    assert s["nnz"] == g["nnz"] and s["hash"] == g["hash"]
+    assert abs(s["sum"] - g["sum"]) <= 1e-6 * abs(g["sum"]) and abs(s["wsum"] - g["wsum"]) <= 1e-6 * abs(g["wsum"])
+
+
 def test_classify_matches_oracle(handle):
     A = synth_csr(20000, 23, 2)
     dA = to_hs(A).toGpuCSR()

@@ -64,6 +64,30 @@ def test_rmcl_synthetic_graph_three_iterations():
     assert np.allclose(rs, 1.0, atol=1e-4)                                # every row is a distribution again
 
 
+def test_sharded_rmcl_single_rank_matches_gpuRmclIter():
+    """dist.ShardedRMCL at world size 1 (device-resident loop: hip_gpuSpMM + hip_rmcl_prune per step, torch tensors
+    as the replicated Mt) against hip_gpuRmclIter on the same graph."""
+    import torch
+    from sparse_matrix_with_flops_amd.dist import HipEngine, ShardedRMCL
+    A = synth_csr(12000, 57, 2)
+    ri = np.repeat(np.arange(A.rows, dtype=np.int32), np.diff(A.rowPtr))
+    Mt = po.rmcl_init(A.rows, A.cols, A.colInd, ri, np.ones_like(A.values))
+    host = (Mt.rowPtr, Mt.colInd, Mt.values, Mt.rows, Mt.cols)
+    job = ShardedRMCL(HipEngine(0), host, host)
+    job.iterate(3)
+    rp, ci, v = job.result_host()
+    torch.cuda.synchronize()
+    want = hs.gpuRmclIter(3, to_hs(Mt), to_hs(Mt))
+    gl, wl = np.diff(rp), np.diff(want.rowPtr)
+    assert np.mean(gl != wl) < 1e-3 and abs(len(ci) - want.nnz) <= max(20, want.nnz // 2000)
+    rs = np.add.reduceat(v, rp[:-1][gl > 0])
+    assert np.allclose(rs, 1.0, atol=1e-4)
+    agree = 0
+    for r in np.nonzero(gl == wl)[0][:1000]:          # a threshold tie may swap one entry of a row; most rows are identical
+        agree += np.array_equal(np.sort(ci[rp[r]:rp[r + 1]]), np.sort(want.colInd[want.rowPtr[r]:want.rowPtr[r + 1]]))
+    assert agree >= 990
+
+
 def test_cpp_mirror_runs_the_reference_test_protocol():
     """tests/cpp/testGpuSpMM.cc == tests/testGpuSpMM.cc + nrmcl.cc of the reference, built on the C++ mirror."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])

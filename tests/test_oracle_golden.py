@@ -122,6 +122,18 @@ def test_headline_instance_numbers():
     assert META["synth"]["262144_42_2"]["nnz"] == ka["nnzC"]
 
 
+def test_headline_1m_instance_numbers():
+    """bench.py's default workload (1 048 576 rows, seed 43): generator pinned against what the real reference
+    computed for it (tests/golden/make_golden.py); the full product is checked on the GPU side."""
+    g = META["synth"]["1048576_43_2"]
+    A = synth_csr(g["m"], g["seed"], g["base"])
+    assert A.nnz == g["nnzA"]
+    f = po.row_flops(A, A)
+    assert int(f.sum()) == g["P"] and int(f.max()) == g["max_row_flops"]
+    pref = np.concatenate([[0], np.cumsum(f)])
+    assert [int(x) for x in po.equal_partition64(pref, 8)] == g["partition8"]
+
+
 def test_gpu_bin_ids_and_classify():
     # dqueueId edges (mindex2-cuda/flops.cu:39-47)
     L = po.lib()
