@@ -120,6 +120,7 @@ struct HostMirror {                 // one small device block + its pinned host 
   int err;
   int scratch2[2];                  // counts of the 513-2048 / 2049-4096 rows when a classification is unpacked
   int qctr[8];                      // work-queue heads of the block-per-row kernels (zeroed with the rest per call)
+  int slotBase[NSLOTS];             // first position of every layout slot in rowIds (written by k_bin_scan)
   unsigned long long totalP;
   unsigned long long nnzC64;
 };
@@ -179,8 +180,8 @@ static int ws_ensure(spgemm_handle* h, int m) {
   const size_t ntile = (cap + 1 + SCAN_TILE - 1) / SCAN_TILE + 1;
   HIPCHK(hipMalloc((void**)&h->rowFlops, sizeof(int) * cap));
   HIPCHK(hipMalloc((void**)&h->binId, cap));
-  HIPCHK(hipMalloc((void**)&h->blockHist, sizeof(int) * nblk * NBINS));
-  HIPCHK(hipMalloc((void**)&h->blockOff, sizeof(int) * nblk * NBINS));
+  HIPCHK(hipMalloc((void**)&h->blockHist, sizeof(int) * nblk * NSLOTS));
+  HIPCHK(hipMalloc((void**)&h->blockOff, sizeof(int) * nblk * NSLOTS));
   HIPCHK(hipMalloc((void**)&h->rowIds, sizeof(int) * cap));
   HIPCHK(hipMalloc((void**)&h->tileSum, sizeof(unsigned long long) * ntile));
   HIPCHK(hipMalloc((void**)&h->blockP, sizeof(unsigned long long) * nblk));
@@ -358,10 +359,10 @@ static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, con
                          h->binId, h->blockHist, h->blockP, dIC); }
     { KTimer t(h, SPGEMM_K_BIN_SCAN);
       hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, h->stream, nblk, h->blockHist, h->blockOff,
-                         h->dsmall->binPtr, h->blockP, &h->dsmall->totalP); }
+                         h->dsmall->binPtr, h->dsmall->slotBase, h->blockP, &h->dsmall->totalP); }
     { KTimer t(h, SPGEMM_K_SCATTER);
       hipLaunchKernelGGL(k_scatter_rows, dim3(nblk), dim3(K1_THREADS), 0, h->stream, m, h->binId, h->blockOff,
-                         h->rowIds); }
+                         h->dsmall->slotBase, h->rowIds); }
   }
   HIPCHK(hipGetLastError());
   return SPGEMM_OK;

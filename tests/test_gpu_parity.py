@@ -146,6 +146,12 @@ def test_classify_matches_oracle(handle):
         lo, hi = max(hv[b] - 1, 0), hv[b + 1] - 1
         mine, theirs = rowIds[lo:hi], o_ids[lo:hi]
         assert np.array_equal(np.sort(mine), np.sort(theirs)), b
+    # rows above 4096 products close the array, heaviest size class (power of two) first: the work queue of the
+    # block-per-row kernels starts with them
+    nbig = int((flops > 4096).sum())
+    if nbig:
+        cls = np.floor(np.log2(flops[rowIds[-nbig:]])).astype(int)
+        assert np.all(flops[rowIds[-nbig:]] > 4096) and np.all(np.diff(cls) <= 0)
     # dflops = scan of the flops in drowIds order
     assert dflops[0] == 0 and np.array_equal(np.diff(dflops.astype(np.int64)), flops[rowIds])
     # binned SpGEMM on that classification == one-shot path == oracle
