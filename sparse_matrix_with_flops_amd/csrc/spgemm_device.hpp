@@ -190,6 +190,44 @@ __device__ __forceinline__ int hash_insert_multi(int* keys, float* vals, int siz
   return claimed;
 }
 
+// table clear, four slots per lane and instruction (sizes are multiples of 4; arrays 16-byte aligned)
+__device__ __forceinline__ void clear_table(int* keys, float* vals, int size, int tid, int nthreads) {
+  const int4 ek = make_int4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
+  const float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid * 4; i < size; i += nthreads * 4) {
+    *reinterpret_cast<int4*>(keys + i) = ek;
+    if (vals) *reinterpret_cast<float4*>(vals + i) = zv;
+  }
+}
+
+// One wave emits the occupied slots [base, base+per) of a finished table: slots into registers, one LDS atomic for
+// the wave's share of the output range [outLo, outHi), stores from the registers (64 consecutive positions a step).
+template <int MAXSTEPS>
+__device__ __forceinline__ void emit_claimed(const int* keys, const float* vals, int base, int per, int* emitted,
+                                             int outLo, int outHi, int* __restrict__ JC, float* __restrict__ C) {
+  const int lane = lane_id();
+  int kx[MAXSTEPS];
+  int cnt = 0;
+#pragma unroll
+  for (int sidx = 0; sidx < MAXSTEPS; ++sidx) {
+    kx[sidx] = sidx * WAVE < per ? keys[base + sidx * WAVE + lane] : EMPTY_KEY;
+    cnt += __popcll(__ballot(kx[sidx] != EMPTY_KEY));
+  }
+  int pos = 0;
+  if (lane == 0) pos = atomicAdd(emitted, cnt);
+  pos = outLo + __builtin_amdgcn_readfirstlane(pos);
+#pragma unroll
+  for (int sidx = 0; sidx < MAXSTEPS; ++sidx) {
+    const bool occ = kx[sidx] != EMPTY_KEY;
+    const unsigned long long mk = __ballot(occ);
+    if (occ) {
+      const int o = pos + mask_rank(mk);
+      if (o < outHi) { JC[o] = kx[sidx]; C[o] = vals[base + sidx * WAVE + lane]; }
+    }
+    pos += __popcll(mk);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1  per-row product count + bin id + per-block bin histogram            (mindex2: gcomputeFlops)
 // One wave owns 64 consecutive rows.  Phase 1: every lane walks the first FL_SHORT entries of its own
@@ -859,7 +897,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ 
     }
     const int size = next_pow2_clamped(2 * cur.x0, 64, TBL);
     const int shift = 32 - log2_pow2(size);
-    for (int i = tid; i < size; i += WAVE * NW) keys[i] = EMPTY_KEY;
+    clear_table(keys, nullptr, size, tid, WAVE * NW);
     if (tid == 0) cnt_s = 0;
     __syncthreads();
     int mine = 0;
@@ -893,10 +931,10 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
                                                          float* __restrict__ C, int* __restrict__ err,
                                                          int* __restrict__ qctr) {
   __shared__ __attribute__((aligned(16))) int keys[TBL];
-  __shared__ float vals[TBL];
+  __shared__ __attribute__((aligned(16))) float vals[TBL];
   __shared__ RowStage<NW, U> st;
-  __shared__ int red[NW];
   __shared__ int qslot;
+  __shared__ int emitted;                        // output positions handed out so far in this row (NW > 1)
   const int tid = threadIdx.x;
   constexpr int T = WAVE * NW;
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
@@ -926,7 +964,8 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
     const int want = cur.x1 - off;                      // exact distinct count from the symbolic pass
     const int size = next_pow2_clamped(2 * want, T > 64 ? T : 64, TBL);
     const int shift = 32 - log2_pow2(size);
-    for (int i = tid; i < size; i += T) { keys[i] = EMPTY_KEY; vals[i] = 0.f; }
+    clear_table(keys, vals, size, tid, T);
+    if (NW > 1 && tid == 0) emitted = 0;
     __syncthreads();
     STAMP(2);
     for_each_product<NW, U, true>(st, cur.as, cur.ae, JA, VA, IB, JB, VB,
@@ -935,29 +974,28 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
     }, pc STAMP_ARGS);
     STAMP(3);
     // compaction: wave w sweeps the contiguous slots [w*per, w*per+per) 64 at a time, so that a wave's stores
-    // land on consecutive output positions.  One wave: a single pass; several waves: count, scan, write.
+    // land on consecutive output positions.  One wave: a single pass.  Several waves: a wave reads its slots into
+    // registers, claims its share of the row's output range with ONE LDS atomic (any order inside a row is a valid
+    // CSR row) and emits from the registers: no counting sweep, no block scan, no barrier.
     const int per = size / NW;
     const int lane = lane_id(), w = tid >> 6;
-    int total;
-    int pos = off;
-    if (NW > 1) {
-      int mine = 0;
-      for (int i = lane; i < per; i += WAVE) mine += keys[w * per + i] != EMPTY_KEY;
-      const int wtot = wave_sum(mine);
-      pos = off + block_excl_scan<NW>(lane == 0 ? wtot : 0, red, &total);
-      pos = __builtin_amdgcn_readfirstlane(pos);
+    if (NW == 1) {
+      int pos = off;
+      for (int i0 = 0; i0 < per; i0 += WAVE) {
+        const int sl = i0 + lane;
+        const int kx = keys[sl];
+        const bool occ = kx != EMPTY_KEY;
+        const unsigned long long mk = __ballot(occ);
+        if (occ) { const int o = pos + mask_rank(mk); JC[o] = kx; C[o] = vals[sl]; }
+        pos += __popcll(mk);
+      }
+      if (tid == 0 && pos - off != want) atomicOr(err, ERRF_COUNT_MISMATCH);
+      __syncthreads();
+    } else {
+      emit_claimed<TBL / NW / WAVE>(keys, vals, w * per, per, &emitted, off, off + want, JC, C);
+      __syncthreads();
+      if (tid == 0 && emitted != want) atomicOr(err, ERRF_COUNT_MISMATCH);
     }
-    for (int i0 = 0; i0 < per; i0 += WAVE) {
-      const int sl = w * per + i0 + lane;
-      const int kx = keys[sl];
-      const bool occ = kx != EMPTY_KEY;
-      const unsigned long long mk = __ballot(occ);
-      if (occ) { const int o = pos + mask_rank(mk); JC[o] = kx; C[o] = vals[sl]; }
-      pos += __popcll(mk);
-    }
-    if (NW == 1) total = pos - off;
-    if (tid == 0 && total != want) atomicOr(err, ERRF_COUNT_MISMATCH);
-    __syncthreads();
     STAMP(4);
     cur = nxt;
     if (NW == 1) { nxt = nn; pc = pn; }
@@ -1014,6 +1052,7 @@ struct BigHashShared {
   RowStage<BIG_NW, BIG_U> st;
   int red[BIG_NW];
   int spillCnt[BH_MAXCLS];
+  int emitted;
 };
 
 __device__ __forceinline__ int block_sum_16(int v, int* red) {
@@ -1221,7 +1260,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
     STAMP(0);
     const int row = rowIds[first + q];
     const int as = IA[row], ae = IA[row + 1];
-    int outBase = IC[row];
+    const int outBase = IC[row];
     const int outEnd = IC[row + 1];
     const int want = outEnd - outBase;
     const unsigned npass = (unsigned)((want + bhCap - 1) / bhCap);
@@ -1235,8 +1274,9 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
     const int shift = 0;
     const int per = size / BIG_NW;
     for (unsigned pass = 0; pass < npass; ++pass) {
-      for (int i = tid; i < size; i += BIG_THREADS) { sh.keys[i] = EMPTY_KEY; sh.vals[i] = 0.f; }
+      clear_table(sh.keys, sh.vals, size, tid, BIG_THREADS);
       if (pass == 0 && tid < BH_MAXCLS) sh.spillCnt[tid] = 0;
+      if (pass == 0 && tid == 0) sh.emitted = 0;
       __syncthreads();
       STAMP(1);
       if (pass == 0 || !useSpill) {
@@ -1298,26 +1338,13 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
         __syncthreads();
         STAMP(3);
       }
-      // compaction: wave w sweeps slots [w*per, w*per+per), 64 per step -> coalesced stores
-      int mine = 0;
-      for (int i = lane; i < per; i += WAVE) mine += sh.keys[w * per + i] != EMPTY_KEY;
-      const int wtot = wave_sum(mine);
-      int total;
-      int pos = outBase + block_excl_scan<BIG_NW>(lane == 0 ? wtot : 0, sh.red, &total);
-      pos = __builtin_amdgcn_readfirstlane(pos);
-      for (int i0 = 0; i0 < per; i0 += WAVE) {
-        const int sl = w * per + i0 + lane;
-        const int kx = sh.keys[sl];
-        const bool occ = kx != EMPTY_KEY;
-        const unsigned long long mk = __ballot(occ);
-        if (occ) { const int o = pos + mask_rank(mk); if (o < outEnd) { JC[o] = kx; C[o] = sh.vals[sl]; } }
-        pos += __popcll(mk);
-      }
-      outBase += total;
+      // compaction: wave w emits the slots [w*per, w*per+per); its share of the row's output range comes from one
+      // LDS atomic (the counter runs on across the passes of a row)
+      emit_claimed<BH_SLOTS / BIG_NW / WAVE>(sh.keys, sh.vals, w * per, per, &sh.emitted, outBase, outEnd, JC, C);
       __syncthreads();
       STAMP(4);
     }
-    if (tid == 0 && outBase != outEnd) atomicOr(err, ERRF_COUNT_MISMATCH);
+    if (tid == 0 && sh.emitted != want) atomicOr(err, ERRF_COUNT_MISMATCH);
     __syncthreads();
   }
   STAMP(0);
