@@ -42,18 +42,31 @@ __host__ __device__ __forceinline__ int bin_of(unsigned long long f) {
   return 8;
 }
 
-// Layout slots of the row-id array: bins 0..7 keep their place; the rows of the last bin are split into NSUB size
-// classes (4097-8191, 8192-16383, ... by powers of two) laid out LARGEST FIRST, so that the work queue of the
-// block-per-row kernels hands out the heavy rows first and the kernel does not end on one of them
-// (measured: k_num_bighash 1.58 -> 1.48 ms at 1 M rows).
-constexpr int NSUB = 8;
-constexpr int NSLOTS = NBINS - 1 + NSUB;
+// Layout slots of the row-id array (finer than the bins; a bin is one or more consecutive slots):
+//   slots 0..4  = bins 0..4
+//   slots 5, 6  = bin 5 split at 256 products: rows up to 256 products need a 512-slot table, so their wave-per-row
+//                 kernel fits 24 blocks per CU instead of 16 (measured on the symbolic kernel: 16 -> 24 waves/CU is
+//                 17 % faster, 32 is slower again)
+//   slots 7, 8  = bins 6, 7
+//   slots 9..15 = the last bin split into NSUB size classes (4097-8191, 8192-16383, ... by powers of two) laid out
+//                 LARGEST FIRST, so that the work queue of the block-per-row kernels hands out the heavy rows first
+//                 and the kernel does not end on one of them (measured: k_num_bighash 1.58 -> 1.48 ms at 1 M rows)
+constexpr int NSUB = 7;
+constexpr int SLOT_H1A = 5, SLOT_H1B = 6, SLOT_H4 = 7, SLOT_H8 = 8, SLOT_BIG0 = 9;
+constexpr int NSLOTS = SLOT_BIG0 + NSUB;
+constexpr int H1A_MAX = 256;
 __host__ __device__ __forceinline__ int slot_of(unsigned long long f) {
   const int b = bin_of(f);
-  if (b < NBINS - 1) return b;
+  if (b < 5) return b;
+  if (b == 5) return f <= (unsigned)H1A_MAX ? SLOT_H1A : SLOT_H1B;
+  if (b < NBINS - 1) return b + 1;
   int lg = 12;                                        // f >= 4097
   while (lg < 12 + NSUB - 1 && (f >> (lg + 1)) != 0) ++lg;
-  return NBINS - 1 + (NSUB - 1 - (lg - 12));
+  return SLOT_BIG0 + (NSUB - 1 - (lg - 12));
+}
+// last slot of a bin
+__host__ __device__ __forceinline__ int last_slot_of_bin(int b) {
+  return b < 5 ? b : b == 5 ? SLOT_H1B : b < NBINS - 1 ? b + 1 : NSLOTS - 1;
 }
 
 // error flag bits written by kernels into Workspace::d_err
@@ -277,12 +290,12 @@ __global__ __launch_bounds__(K1_THREADS) void k_row_flops(
     if (b <= 1) IC[r] = b;                           // 0 products -> 0 entries, 1 product -> 1 entry
   }
 #pragma unroll
-  for (int q = 0; q < NBINS - 1; ++q) {
+  for (int q = 0; q < SLOT_BIG0; ++q) {
     const unsigned long long mk = __ballot(b == q);
     if (lane == 0 && mk) atomicAdd(&hist[q], __popcll(mk));
   }
-  if (__ballot(b >= NBINS - 1)) {                    // big rows are rare: most waves skip their size classes
-    for (int q = NBINS - 1; q < NSLOTS; ++q) {
+  if (__ballot(b >= SLOT_BIG0)) {                    // big rows are rare: most waves skip their size classes
+    for (int q = SLOT_BIG0; q < NSLOTS; ++q) {
       const unsigned long long mk = __ballot(b == q);
       if (lane == 0 && mk) atomicAdd(&hist[q], __popcll(mk));
     }
@@ -339,11 +352,9 @@ __global__ __launch_bounds__(1024) void k_bin_scan(int nblk, const int* __restri
     *totalP = ptot;
     int run = 0;
     binPtr[0] = 0;
-    for (int sl = 0; sl < NSLOTS; ++sl) {
-      slotBase[sl] = run;
-      run += slotTot[sl];
-      if (sl < NBINS - 1 || sl == NSLOTS - 1) binPtr[min(sl, NBINS - 1) + 1] = run;   // the last bin ends after its classes
-    }
+    for (int sl = 0; sl < NSLOTS; ++sl) { slotBase[sl] = run; run += slotTot[sl]; }
+    slotBase[NSLOTS] = run;
+    for (int b = 0; b < NBINS; ++b) binPtr[b + 1] = slotBase[last_slot_of_bin(b) + 1];
   }
 }
 

@@ -118,9 +118,9 @@ DevPool& pool() { static DevPool* p = new DevPool(); return *p; }
 struct HostMirror {                 // one small device block + its pinned host twin, copied once per phase
   int binPtr[NBINS + 1];
   int err;
-  int scratch2[2];                  // counts of the 513-2048 / 2049-4096 rows when a classification is unpacked
+  int scratch2[3];                  // counts of the 513-2048 / 2049-4096 / 65-256 rows when a classification is unpacked
   int qctr[8];                      // work-queue heads of the block-per-row kernels (zeroed with the rest per call)
-  int slotBase[NSLOTS];             // first position of every layout slot in rowIds (written by k_bin_scan)
+  int slotBase[NSLOTS + 1];         // first position of every layout slot in rowIds, [NSLOTS] = m (k_bin_scan)
   unsigned long long totalP;
   unsigned long long nnzC64;
 };
@@ -161,6 +161,7 @@ struct spgemm_handle {
   int2* spill = nullptr;
   int spill_blocks = 0;
   int bhCap = BH_CAP;
+  int h1sym = 24;                    // blocks per CU of the wave-per-row symbolic kernel (SPGEMM_H1SYM, experiments)
   spgemm_stats stats;
 };
 
@@ -216,6 +217,7 @@ extern "C" int spgemm_hip_create(spgemm_handle** out, int device) {
   for (auto& e : h->kev) HIPCHK(hipEventCreate(&e));
   for (auto& u : h->kused) u = false;
   { const char* e = getenv("SPGEMM_CONCURRENT"); h->serial = !(e && e[0] == '1'); }
+  { const char* e = getenv("SPGEMM_H1SYM"); if (e) { const int c = atoi(e); if (c >= 1 && c <= 32) h->h1sym = c; } }
   { const char* e = getenv("SPGEMM_BHCAP"); if (e) { const int c = atoi(e); if (c >= 1024 && c <= BH_CAP_MAX) h->bhCap = c; } }
   { const char* e = getenv("SPGEMM_U"); if (e) { const int u = atoi(e); if (u == 2 || u == 4 || u == 8) h->U = u; } }
   for (auto& st : h->side) {
@@ -388,7 +390,10 @@ static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJA, con
     LAUNCH_U(k_sym_hash, 4, 4096, dim3(clampi(m, 1, cu * 8)), dim3(256), st, bp, 6, rowIds, dIA,
              dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 2); }
   { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_SYM_HASH1, st);
-    LAUNCH_U(k_sym_hash, 1, 1024, dim3(clampi(m, 1, cu * 32)), dim3(64), st, bp, 5, rowIds, dIA,
+    const int* sb = h->dsmall->slotBase;         // bin 5 = two layout slots: table 512 up to 256 products, 1024 above
+    LAUNCH_U(k_sym_hash, 1, 512, dim3(clampi(m, 1, cu * h->h1sym)), dim3(64), st, sb, SLOT_H1A, rowIds, dIA,
+             dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 3);
+    LAUNCH_U(k_sym_hash, 1, 1024, dim3(clampi(m, 1, cu * h->h1sym)), dim3(64), st, sb, SLOT_H1B, rowIds, dIA,
              dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 3); }
   { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_SYM_G16, st);
     hipLaunchKernelGGL((k_sym_g16<128, 4>), dim3(clampi(cdiv(m, 16), 1, cu * 16)), dim3(256), 0, st, bp, 4,
@@ -447,8 +452,13 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const int* dJA, cons
     LAUNCH_U(k_num_hash, 4, 4096, dim3(clampi(rows(6, 7), 1, cu * 4)), dim3(256), st, bp, 6,
              rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 6); }
   if (rows(5, 6) > 0) { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_NUM_HASH1, st);
-    LAUNCH_U(k_num_hash, 1, 1024, dim3(clampi(rows(5, 6), 1, cu * 16)), dim3(64), st, bp, 5,
-             rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 7); }
+    const int* sb = h->dsmall->slotBase;
+    const int* hs_ = h->mirror.slotBase;
+    const int na = hs_[SLOT_H1A + 1] - hs_[SLOT_H1A], nb = hs_[SLOT_H1B + 1] - hs_[SLOT_H1B];
+    if (na > 0) LAUNCH_U(k_num_hash, 1, 512, dim3(clampi(na, 1, cu * 24)), dim3(64), st, sb, SLOT_H1A,
+                         rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 7);
+    if (nb > 0) LAUNCH_U(k_num_hash, 1, 1024, dim3(clampi(nb, 1, cu * 16)), dim3(64), st, sb, SLOT_H1B,
+                         rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 7); }
   if (rows(4, 5) > 0) { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_NUM_G16, st);
     hipLaunchKernelGGL((k_num_g16<128, 4>), dim3(clampi(cdiv(rows(4, 5), 16), 1, cu * 16)), dim3(256), 0, st,
                        bp, 4, rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err); }
@@ -691,7 +701,7 @@ extern "C" int hip_gpuFlopsClassify(spgemm_handle* h, const int* dIA, const int*
 __global__ void k_unpack_classify(int m, const int* __restrict__ rowIds, const int* __restrict__ dflops,
                                   int* __restrict__ rowFlops, int* __restrict__ IC, int lo6, int* __restrict__ n67) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  int is6 = 0, is7 = 0;
+  int is6 = 0, is7 = 0, is5a = 0;
   if (q < m) {
     const int r = rowIds[q];
     // dflops is an int scan (like the reference's): differences stay exact modulo 2^32
@@ -700,15 +710,23 @@ __global__ void k_unpack_classify(int m, const int* __restrict__ rowIds, const i
     if (f <= 1u) IC[r] = (int)f;
     is6 = (q >= lo6 && f <= 2048u) ? 1 : 0;
     is7 = (q >= lo6 && f > 2048u && f <= 4096u) ? 1 : 0;
+    is5a = (f > 64u && f <= (unsigned)smf::H1A_MAX) ? 1 : 0;
   }
-  const unsigned long long m6 = __ballot(is6), m7 = __ballot(is7);
-  if (smf::lane_id() == 0) { if (m6) atomicAdd(&n67[0], __popcll(m6)); if (m7) atomicAdd(&n67[1], __popcll(m7)); }
+  const unsigned long long m6 = __ballot(is6), m7 = __ballot(is7), m5 = __ballot(is5a);
+  if (smf::lane_id() == 0) {
+    if (m6) atomicAdd(&n67[0], __popcll(m6));
+    if (m7) atomicAdd(&n67[1], __popcll(m7));
+    if (m5) atomicAdd(&n67[2], __popcll(m5));
+  }
 }
 
-__global__ void k_binptr_from_hv(int* binPtr, int h2, int h3, int h4, int h5, int h6, int h7, int m, const int* n67) {
+__global__ void k_binptr_from_hv(int* binPtr, int* slotBase, int h2, int h3, int h4, int h5, int h6, int h7, int m,
+                                 const int* n67) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     binPtr[0] = 0; binPtr[1] = h2 - 1; binPtr[2] = h3 - 1; binPtr[3] = h4 - 1; binPtr[4] = h5 - 1;
     binPtr[5] = h6 - 1; binPtr[6] = h7 - 1; binPtr[7] = h7 - 1 + n67[0]; binPtr[8] = binPtr[7] + n67[1]; binPtr[9] = m;
+    // the two layout slots of bin 5 (the classification came from hip_gpuFlopsClassify: <=256 products first)
+    slotBase[smf::SLOT_H1A] = binPtr[5]; slotBase[smf::SLOT_H1B] = binPtr[5] + n67[2]; slotBase[smf::SLOT_H4] = binPtr[6];
   }
 }
 
@@ -723,7 +741,7 @@ static int unpack_classification(spgemm_handle* h, int m, const PreClass& pre, i
     int* n67 = h->dsmall->scratch2;
     hipLaunchKernelGGL(k_unpack_classify, dim3(cdiv(m, 256)), dim3(256), 0, h->stream, m, pre.drowIds, pre.dflops,
                        h->rowFlops, dIC, hv[7] - 1, n67);
-    hipLaunchKernelGGL(k_binptr_from_hv, dim3(1), dim3(64), 0, h->stream, h->dsmall->binPtr, hv[2], hv[3], hv[4], hv[5],
+    hipLaunchKernelGGL(k_binptr_from_hv, dim3(1), dim3(64), 0, h->stream, h->dsmall->binPtr, h->dsmall->slotBase, hv[2], hv[3], hv[4], hv[5],
                        hv[6], hv[7], m, n67);
   }
   HIPCHK(hipGetLastError());
