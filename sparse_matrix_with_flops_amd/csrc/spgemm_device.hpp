@@ -203,6 +203,110 @@ __device__ __forceinline__ int hash_insert_multi(int* keys, float* vals, int siz
   return claimed;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Numeric accumulation.  Measured on gfx950 (tools/micro/lds_atomics.hip): ds_add_f32 costs ~3 cycles PER ACTIVE LANE
+// (195 cycles for a full wave, and lanes parked on a dummy address count as active), while ds_cmpst b32/b64 and plain
+// reads cost <= 26 cycles per wave instruction.  So the tables of the numeric kernels hold (key, value) PAIRS in one
+// 64-bit word and a product that meets an empty slot deposits key AND value with a single 64-bit CAS -- on these
+// matrices 9 out of 10 products are the first of their column.  Only a product that finds its key already present
+// needs a float add, issued under the EXEC mask (cost = 3 cycles x the few lanes that need it).
+// ------------------------------------------------------------------------------------------------
+typedef unsigned long long slot_t;                       // low half: key (column), high half: value bits
+constexpr slot_t EMPTY_SLOT = 0x00000000FFFFFFFFull;      // {EMPTY_KEY, 0.0f}
+__device__ __forceinline__ slot_t make_slot(int col, float v) {
+  return (slot_t)(unsigned)col | ((slot_t)__float_as_uint(v) << 32);
+}
+__device__ __forceinline__ int slot_key(slot_t sl) { return (int)(unsigned)sl; }
+__device__ __forceinline__ float slot_val(slot_t sl) { return __uint_as_float((unsigned)(sl >> 32)); }
+__device__ __forceinline__ float* slot_val_ptr(slot_t* tab, unsigned i) { return reinterpret_cast<float*>(tab + i) + 1; }
+
+// one product per lane, divergent callers (small-row kernels)
+__device__ __forceinline__ void hash_accum(slot_t* tab, int size, int shift, int c, float v, int* err) {
+  unsigned h = ((unsigned)c * 2654435761u) >> shift;
+  const unsigned mask = (unsigned)size - 1u;
+  const slot_t mine = make_slot(c, v);
+  for (int probe = 0; probe < size; ++probe) {
+    const slot_t old = atomicCAS(&tab[h], EMPTY_SLOT, mine);
+    if (old == EMPTY_SLOT) return;
+    if (slot_key(old) == c) { atomicAdd(slot_val_ptr(tab, h), v); return; }
+    h = (h + 1u) & mask;
+  }
+  atomicOr(err, ERRF_TABLE_FULL);
+}
+
+// U products per lane in lock step, wave-uniform control flow.  Lanes without work aim their CAS at a private
+// 8-byte dummy (a CAS costs the same with any lane count; the float add below does not, hence its EXEC mask).
+template <int U, bool POW2 = true>
+__device__ __forceinline__ void hash_accum_multi(slot_t* tab, int size, int shift, const bool (&act)[U],
+                                                 const int (&col)[U], const float (&val)[U], slot_t* dummy, int* err) {
+  const unsigned mask = (unsigned)size - 1u;
+  unsigned h[U];
+  bool pend[U], dup[U];
+  slot_t mine[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const unsigned hv = (unsigned)col[u] * 2654435761u;
+    h[u] = POW2 ? hv >> shift : __umulhi(hv, (unsigned)size);
+    pend[u] = act[u];
+    dup[u] = false;
+    mine[u] = make_slot(col[u], val[u]);
+  }
+  bool done = false;
+  for (int probe = 0; probe < size && !done; ++probe) {
+    slot_t old[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) old[u] = atomicCAS(pend[u] ? &tab[h[u]] : dummy, EMPTY_SLOT, mine[u]);
+    bool more = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool fresh = pend[u] && old[u] == EMPTY_SLOT;
+      const bool same = pend[u] && slot_key(old[u]) == col[u];
+      const bool fin = fresh || same;
+      dup[u] = dup[u] || same;
+      const unsigned nh = POW2 ? ((h[u] + 1u) & mask) : (h[u] + 1u == (unsigned)size ? 0u : h[u] + 1u);
+      h[u] = (pend[u] && !fin) ? nh : h[u];
+      pend[u] = pend[u] && !fin;
+      more = more || pend[u];
+    }
+    done = !__any(more);
+  }
+  if (!done) atomicOr(err, ERRF_TABLE_FULL);
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (dup[u]) atomicAdd(slot_val_ptr(tab, h[u]), val[u]);
+}
+
+// float add into an LDS word by read + 32-bit CAS (retry on interference): ~2 cheap LDS ops instead of a
+// ds_add_f32 over a full wave.  U per lane in lock step; lanes without work aim at a private dummy.
+template <int U>
+__device__ __forceinline__ void lds_fadd_multi(float* acc, const int (&idx)[U], const bool (&ok)[U], const float (&v)[U],
+                                               int* dummy) {
+  int* ia = reinterpret_cast<int*>(acc);
+  int old[U];
+  bool pend[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) { pend[u] = ok[u]; old[u] = ia[ok[u] ? idx[u] : 0]; }
+  for (;;) {
+    int got[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      got[u] = atomicCAS(pend[u] ? &ia[idx[u]] : dummy, old[u], __float_as_int(__int_as_float(old[u]) + v[u]));
+    bool more = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      pend[u] = pend[u] && got[u] != old[u];
+      old[u] = got[u];
+      more = more || pend[u];
+    }
+    if (!__any(more)) break;
+  }
+}
+
+// slot-table clear, two slots per lane and instruction
+__device__ __forceinline__ void clear_slots(slot_t* tab, int size, int tid, int nthreads) {
+  for (int i = tid * 2; i < size; i += nthreads * 2) *reinterpret_cast<ulonglong2*>(tab + i) = make_ulonglong2(EMPTY_SLOT, EMPTY_SLOT);
+}
+
 // table clear, four slots per lane and instruction (sizes are multiples of 4; arrays 16-byte aligned)
 __device__ __forceinline__ void clear_table(int* keys, float* vals, int size, int tid, int nthreads) {
   const int4 ek = make_int4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
@@ -216,26 +320,26 @@ __device__ __forceinline__ void clear_table(int* keys, float* vals, int size, in
 // One wave emits the occupied slots [base, base+per) of a finished table: slots into registers, one LDS atomic for
 // the wave's share of the output range [outLo, outHi), stores from the registers (64 consecutive positions a step).
 template <int MAXSTEPS>
-__device__ __forceinline__ void emit_claimed(const int* keys, const float* vals, int base, int per, int* emitted,
+__device__ __forceinline__ void emit_claimed(const slot_t* tab, int base, int per, int* emitted,
                                              int outLo, int outHi, int* __restrict__ JC, float* __restrict__ C) {
   const int lane = lane_id();
-  int kx[MAXSTEPS];
+  slot_t sl[MAXSTEPS];
   int cnt = 0;
 #pragma unroll
   for (int sidx = 0; sidx < MAXSTEPS; ++sidx) {
-    kx[sidx] = sidx * WAVE < per ? keys[base + sidx * WAVE + lane] : EMPTY_KEY;
-    cnt += __popcll(__ballot(kx[sidx] != EMPTY_KEY));
+    sl[sidx] = sidx * WAVE < per ? tab[base + sidx * WAVE + lane] : EMPTY_SLOT;
+    cnt += __popcll(__ballot(slot_key(sl[sidx]) != EMPTY_KEY));
   }
   int pos = 0;
   if (lane == 0) pos = atomicAdd(emitted, cnt);
   pos = outLo + __builtin_amdgcn_readfirstlane(pos);
 #pragma unroll
   for (int sidx = 0; sidx < MAXSTEPS; ++sidx) {
-    const bool occ = kx[sidx] != EMPTY_KEY;
+    const bool occ = slot_key(sl[sidx]) != EMPTY_KEY;
     const unsigned long long mk = __ballot(occ);
     if (occ) {
       const int o = pos + mask_rank(mk);
-      if (o < outHi) { JC[o] = kx[sidx]; C[o] = vals[base + sidx * WAVE + lane]; }
+      if (o < outHi) { JC[o] = slot_key(sl[sidx]); C[o] = slot_val(sl[sidx]); }
     }
     pos += __popcll(mk);
   }
@@ -442,8 +546,7 @@ __global__ __launch_bounds__(256) void k_num_small(const int* __restrict__ binPt
                                                     const int* __restrict__ IC, int* __restrict__ JC,
                                                     float* __restrict__ C, int* __restrict__ err) {
   constexpr int GROUPS = 256 / G;
-  __shared__ int keys[GROUPS][TBL];
-  __shared__ float vals[GROUPS][TBL];
+  __shared__ slot_t tab[GROUPS][TBL];          // (column, value) pairs
   const int tid = threadIdx.x, g = tid / G, gl = tid % G;
   const int first = binPtr[binLo], count = binPtr[binHi] - first;
   const int iters = (count + GROUPS - 1) / GROUPS;
@@ -454,7 +557,7 @@ __global__ __launch_bounds__(256) void k_num_small(const int* __restrict__ binPt
     const int F = live ? rowFlops[row] : 1;
     const int size = next_pow2_clamped(2 * F, 8, TBL);
     const int shift = 32 - log2_pow2(size);
-    for (int i = gl; i < size; i += G) { keys[g][i] = EMPTY_KEY; vals[g][i] = 0.f; }
+    for (int i = gl; i < size; i += G) tab[g][i] = EMPTY_SLOT;
     wave_lds_sync();
     if (live) {
       const int as = IA[row], ae = IA[row + 1];
@@ -462,11 +565,7 @@ __global__ __launch_bounds__(256) void k_num_small(const int* __restrict__ binPt
         const int j = JA[ap];
         const float a = VA[ap];
         const int bs = IB[j], be = IB[j + 1];
-        for (int bp = bs + gl; bp < be; bp += G) {
-          bool isnew;
-          const int s = hash_insert(keys[g], size, shift, JB[bp], &isnew, err);
-          atomicAdd(&vals[g][s], a * VB[bp]);
-        }
+        for (int bp = bs + gl; bp < be; bp += G) hash_accum(tab[g], size, shift, JB[bp], a * VB[bp], err);
       }
     }
     wave_lds_sync();
@@ -475,14 +574,13 @@ __global__ __launch_bounds__(256) void k_num_small(const int* __restrict__ binPt
     const int want = live ? IC[row + 1] - off : 0;
     int written = 0;
     for (int i0 = 0; i0 < size; i0 += G) {
-      const int i = i0 + gl;
-      const int kx = keys[g][i];
-      const bool occ = live && kx != EMPTY_KEY;
+      const slot_t sv = tab[g][i0 + gl];
+      const bool occ = live && slot_key(sv) != EMPTY_KEY;
       const unsigned long long mk = __ballot(occ);
       const int shiftg = lane_id() - gl;
       const unsigned long long gm = (G == 64) ? mk : ((mk >> shiftg) & ((1ull << G) - 1ull));
       const int rank = __popcll(gm & ((1ull << gl) - 1ull));
-      if (occ) { JC[off + written + rank] = kx; C[off + written + rank] = vals[g][i]; }
+      if (occ) { JC[off + written + rank] = slot_key(sv); C[off + written + rank] = slot_val(sv); }
       written += __popcll(gm);
     }
     if (live && gl == 0 && written != want) atomicOr(err, ERRF_COUNT_MISMATCH);
@@ -622,8 +720,7 @@ __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr,
                                                   const float* __restrict__ VB,
                                                   const int* __restrict__ IC, int* __restrict__ JC,
                                                   float* __restrict__ C, int* __restrict__ err) {
-  __shared__ int keys[16][TBL];
-  __shared__ float vals[16][TBL];
+  __shared__ slot_t tab[16][TBL];              // (column, value) pairs
   __shared__ G16Stage st[16];
   const int tid = threadIdx.x, g = tid >> 4, gl = tid & 15;
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
@@ -636,27 +733,22 @@ __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr,
     const int want = live ? IC[row + 1] - off : 0;
     const int size = next_pow2_clamped(2 * want, 16, TBL);
     const int shift = 32 - log2_pow2(size);
-    for (int i = gl; i < size; i += 16) { keys[g][i] = EMPTY_KEY; vals[g][i] = 0.f; }
+    for (int i = gl; i < size; i += 16) tab[g][i] = EMPTY_SLOT;
     wave_lds_sync();
     if (live) {
       g16_walk<U, true>(st[g], gl, IA[row], IA[row + 1], JA, VA, IB, JB, VB, [&](bool active, int col, float v) {
-        if (active) {
-          bool isnew;
-          const int s = hash_insert(keys[g], size, shift, col, &isnew, err);
-          atomicAdd(&vals[g][s], v);
-        }
+        if (active) hash_accum(tab[g], size, shift, col, v, err);
       });
     }
     wave_lds_sync();
     int written = 0;
     for (int i0 = 0; i0 < size; i0 += 16) {
-      const int i = i0 + gl;
-      const int kx = keys[g][i];
-      const bool occ = live && kx != EMPTY_KEY;
+      const slot_t sv = tab[g][i0 + gl];
+      const bool occ = live && slot_key(sv) != EMPTY_KEY;
       const unsigned long long mk = __ballot(occ);
       const unsigned gm = (unsigned)(mk >> (lane_id() - gl)) & 0xffffu;
       const int rank = __popc(gm & ((1u << gl) - 1u));
-      if (occ) { JC[off + written + rank] = kx; C[off + written + rank] = vals[g][i]; }
+      if (occ) { JC[off + written + rank] = slot_key(sv); C[off + written + rank] = slot_val(sv); }
       written += __popc(gm);
     }
     if (live && gl == 0 && written != want) atomicOr(err, ERRF_COUNT_MISMATCH);
@@ -680,7 +772,7 @@ struct RowStage {
   float aval[WAVE * NW];
   int wsum[NW];
   int trip;                // next unclaimed trip of the staged chunk (NW > 1: waves claim trips as they finish)
-  int dummy[WAVE * NW];    // one private word per lane: target of predicated-off atomics
+  slot_t dummy[WAVE * NW]; // one private 8-byte word per lane: target of predicated-off atomics
 };
 
 // first chunk of A entries fetched ahead of time (wave-per-row kernels prefetch the next row's while they work)
@@ -914,7 +1006,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ 
     int mine = 0;
     for_each_product<NW, U, false>(st, cur.as, cur.ae, JA, nullptr, IB, JB, nullptr,
                                    [&](const bool (&act)[U], const int (&col)[U], const float (&val)[U]) {
-      mine += hash_insert_multi<U>(keys, nullptr, size, shift, act, col, val, &st.dummy[threadIdx.x], err);
+      mine += hash_insert_multi<U>(keys, nullptr, size, shift, act, col, val, reinterpret_cast<int*>(&st.dummy[threadIdx.x]), err);
     }, pc);
     const int ws = wave_sum(mine);
     if (NW == 1) {
@@ -941,8 +1033,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
                                                          const int* __restrict__ IC, int* __restrict__ JC,
                                                          float* __restrict__ C, int* __restrict__ err,
                                                          int* __restrict__ qctr) {
-  __shared__ __attribute__((aligned(16))) int keys[TBL];
-  __shared__ __attribute__((aligned(16))) float vals[TBL];
+  __shared__ __attribute__((aligned(16))) slot_t tab[TBL];   // (column, value) pairs
   __shared__ RowStage<NW, U> st;
   __shared__ int qslot;
   __shared__ int emitted;                        // output positions handed out so far in this row (NW > 1)
@@ -975,13 +1066,13 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
     const int want = cur.x1 - off;                      // exact distinct count from the symbolic pass
     const int size = next_pow2_clamped(2 * want, T > 64 ? T : 64, TBL);
     const int shift = 32 - log2_pow2(size);
-    clear_table(keys, vals, size, tid, T);
+    clear_slots(tab, size, tid, T);
     if (NW > 1 && tid == 0) emitted = 0;
     __syncthreads();
     STAMP(2);
     for_each_product<NW, U, true>(st, cur.as, cur.ae, JA, VA, IB, JB, VB,
                                   [&](const bool (&act)[U], const int (&col)[U], const float (&val)[U]) {
-      hash_insert_multi<U>(keys, vals, size, shift, act, col, val, &st.dummy[threadIdx.x], err);
+      hash_accum_multi<U>(tab, size, shift, act, col, val, &st.dummy[threadIdx.x], err);
     }, pc STAMP_ARGS);
     STAMP(3);
     // compaction: wave w sweeps the contiguous slots [w*per, w*per+per) 64 at a time, so that a wave's stores
@@ -993,17 +1084,16 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
     if (NW == 1) {
       int pos = off;
       for (int i0 = 0; i0 < per; i0 += WAVE) {
-        const int sl = i0 + lane;
-        const int kx = keys[sl];
-        const bool occ = kx != EMPTY_KEY;
+        const slot_t sv = tab[i0 + lane];
+        const bool occ = slot_key(sv) != EMPTY_KEY;
         const unsigned long long mk = __ballot(occ);
-        if (occ) { const int o = pos + mask_rank(mk); JC[o] = kx; C[o] = vals[sl]; }
+        if (occ) { const int o = pos + mask_rank(mk); JC[o] = slot_key(sv); C[o] = slot_val(sv); }
         pos += __popcll(mk);
       }
       if (tid == 0 && pos - off != want) atomicOr(err, ERRF_COUNT_MISMATCH);
       __syncthreads();
     } else {
-      emit_claimed<TBL / NW / WAVE>(keys, vals, w * per, per, &emitted, off, off + want, JC, C);
+      emit_claimed<TBL / NW / WAVE>(tab, w * per, per, &emitted, off, off + want, JC, C);
       __syncthreads();
       if (tid == 0 && emitted != want) atomicOr(err, ERRF_COUNT_MISMATCH);
     }
@@ -1033,7 +1123,7 @@ constexpr int BIG_WC = 262144;                 // columns covered by the rank ke
 constexpr int BIG_WORDS = BIG_WC / 32;         // 8192
 constexpr int BIG_WPT = BIG_WORDS / BIG_THREADS;  // 8 words per thread
 constexpr int BIG_CAP = 18432;                 // float accumulators per rank pass (72 KB)
-constexpr int BH_SLOTS = 17408;                // hash kernel: 68 KB keys + 68 KB values (17 x 1024 slots, not a power of two)
+constexpr int BH_SLOTS = 17408;                // hash kernel: 136 KB of (key, value) pairs (17 x 1024 slots, not a power of two)
 constexpr int BH_CAP = 10240;                  // distinct columns per hash pass (load <= 0.6 incl. partition skew; measured
                                                // best of 8704/10240/12800 once later passes stream parked products)
 constexpr int BH_CAP_MAX = 12800;              // SPGEMM_BHCAP may raise the cap to this (load 0.74)
@@ -1058,8 +1148,7 @@ struct BigNumShared {
   int cnt;
 };
 struct BigHashShared {
-  int keys[BH_SLOTS];
-  float vals[BH_SLOTS];
+  slot_t tab[BH_SLOTS];          // (column, value) pairs
   RowStage<BIG_NW, BIG_U> st;
   int red[BIG_NW];
   int spillCnt[BH_MAXCLS];
@@ -1226,11 +1315,11 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
           const int wi = c >> 5;
           rk[u] = sh.prefix[wi] + __popc(sh.bitmap[wi] & ((1u << (c & 31)) - 1u)) - lo;
         }
+        bool ok[BIG_U];
 #pragma unroll
-        for (int u = 0; u < BIG_U; ++u) {          // predicated by value: adding 0 to this lane's own dummy word
-          const bool ok = act[u] && (unsigned)col[u] < (unsigned)n && (unsigned)rk[u] < (unsigned)span;
-          atomicAdd(ok ? &sh.acc[rk[u]] : reinterpret_cast<float*>(&sh.st.dummy[threadIdx.x]), ok ? val[u] : 0.f);
-        }
+        for (int u = 0; u < BIG_U; ++u)
+          ok[u] = act[u] && (unsigned)col[u] < (unsigned)n && (unsigned)rk[u] < (unsigned)span;
+        lds_fadd_multi<BIG_U>(sh.acc, rk, ok, val, reinterpret_cast<int*>(&sh.st.dummy[threadIdx.x]));
       } STAMP_ARGS);
       STAMP(5);
       for (int i = tid; i < span; i += BIG_THREADS) C[outBase + lo + i] = sh.acc[i];
@@ -1285,7 +1374,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
     const int shift = 0;
     const int per = size / BIG_NW;
     for (unsigned pass = 0; pass < npass; ++pass) {
-      clear_table(sh.keys, sh.vals, size, tid, BIG_THREADS);
+      clear_slots(sh.tab, size, tid, BIG_THREADS);
       if (pass == 0 && tid < BH_MAXCLS) sh.spillCnt[tid] = 0;
       if (pass == 0 && tid == 0) sh.emitted = 0;
       __syncthreads();
@@ -1300,7 +1389,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
             cls[u] = npass == 1 ? 0u : bh_class(col[u], npass);
             mine[u] = act[u] && cls[u] == pass;
           }
-          hash_insert_multi<BIG_U, false>(sh.keys, sh.vals, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
+          hash_accum_multi<BIG_U, false>(sh.tab, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
           if (useSpill) {                              // block-uniform; here pass == 0
             for (unsigned c = 1; c < npass; ++c) {
               unsigned long long mk[BIG_U];
@@ -1344,14 +1433,14 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
             const int idx = i0 + BIG_THREADS * BIG_U + u * BIG_THREADS + tid;
             nxt[u] = src[idx < cnt ? idx : 0];
           }
-          hash_insert_multi<BIG_U, false>(sh.keys, sh.vals, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
+          hash_accum_multi<BIG_U, false>(sh.tab, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
         }
         __syncthreads();
         STAMP(3);
       }
       // compaction: wave w emits the slots [w*per, w*per+per); its share of the row's output range comes from one
       // LDS atomic (the counter runs on across the passes of a row)
-      emit_claimed<BH_SLOTS / BIG_NW / WAVE>(sh.keys, sh.vals, w * per, per, &sh.emitted, outBase, outEnd, JC, C);
+      emit_claimed<BH_SLOTS / BIG_NW / WAVE>(sh.tab, w * per, per, &sh.emitted, outBase, outEnd, JC, C);
       __syncthreads();
       STAMP(4);
     }
