@@ -1116,7 +1116,8 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 constexpr int BIG_NW = 16;
 constexpr int BIG_THREADS = BIG_NW * WAVE;
-constexpr int BIG_U = 4;
+constexpr int BIG_U = 4;                        // rounds in flight per wave: bitmap / rank kernels
+constexpr int BH_U = 2;                         // ... and the big-row hash kernel (probe chains: 2 measured better than 4)
 constexpr int SYM_WC = 1 << 20;                // columns per symbolic window (128 KB bitmap)
 constexpr int SYM_WORDS = SYM_WC / 32;
 constexpr int BIG_WC = 262144;                 // columns covered by the rank kernel (32 KB bitmap)
@@ -1149,7 +1150,7 @@ struct BigNumShared {
 };
 struct BigHashShared {
   slot_t tab[BH_SLOTS];          // (column, value) pairs
-  RowStage<BIG_NW, BIG_U> st;
+  RowStage<BIG_NW, BH_U> st;
   int red[BIG_NW];
   int spillCnt[BH_MAXCLS];
   int emitted;
@@ -1380,29 +1381,29 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
       __syncthreads();
       STAMP(1);
       if (pass == 0 || !useSpill) {
-        for_each_product<BIG_NW, BIG_U, true>(sh.st, as, ae, JA, VA, IB, JB, VB,
-                                              [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&val)[BIG_U]) {
-          bool mine[BIG_U];
-          unsigned cls[BIG_U];
+        for_each_product<BIG_NW, BH_U, true>(sh.st, as, ae, JA, VA, IB, JB, VB,
+                                              [&](const bool (&act)[BH_U], const int (&col)[BH_U], const float (&val)[BH_U]) {
+          bool mine[BH_U];
+          unsigned cls[BH_U];
 #pragma unroll
-          for (int u = 0; u < BIG_U; ++u) {
+          for (int u = 0; u < BH_U; ++u) {
             cls[u] = npass == 1 ? 0u : bh_class(col[u], npass);
             mine[u] = act[u] && cls[u] == pass;
           }
-          hash_accum_multi<BIG_U, false>(sh.tab, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
+          hash_accum_multi<BH_U, false>(sh.tab, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
           if (useSpill) {                              // block-uniform; here pass == 0
             for (unsigned c = 1; c < npass; ++c) {
-              unsigned long long mk[BIG_U];
+              unsigned long long mk[BH_U];
               int total = 0;
 #pragma unroll
-              for (int u = 0; u < BIG_U; ++u) { mk[u] = __ballot(act[u] && cls[u] == c); total += __popcll(mk[u]); }
+              for (int u = 0; u < BH_U; ++u) { mk[u] = __ballot(act[u] && cls[u] == c); total += __popcll(mk[u]); }
               if (total) {                             // wave-uniform
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&sh.spillCnt[c], total);
                 base = __builtin_amdgcn_readfirstlane(base);
                 int2* const dst = park + (size_t)(c - 1) * (size_t)stride;
 #pragma unroll
-                for (int u = 0; u < BIG_U; ++u) {
+                for (int u = 0; u < BH_U; ++u) {
                   if (act[u] && cls[u] == c) dst[base + mask_rank(mk[u])] = make_int2(col[u], __float_as_int(val[u]));
                   base += __popcll(mk[u]);
                 }
@@ -1415,25 +1416,25 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
         // stream this class's parked pairs; the next batch is in flight while the current one is inserted
         const int cnt = sh.spillCnt[pass];            // written in pass 0, read-only since its closing barrier
         const int2* const src = park + (size_t)(pass - 1) * (size_t)stride;
-        int2 nxt[BIG_U];
+        int2 nxt[BH_U];
 #pragma unroll
-        for (int u = 0; u < BIG_U; ++u) { const int idx = u * BIG_THREADS + tid; nxt[u] = src[idx < cnt ? idx : 0]; }
-        for (int i0 = 0; i0 < cnt; i0 += BIG_THREADS * BIG_U) {
-          bool mine[BIG_U];
-          int col[BIG_U];
-          float val[BIG_U];
+        for (int u = 0; u < BH_U; ++u) { const int idx = u * BIG_THREADS + tid; nxt[u] = src[idx < cnt ? idx : 0]; }
+        for (int i0 = 0; i0 < cnt; i0 += BIG_THREADS * BH_U) {
+          bool mine[BH_U];
+          int col[BH_U];
+          float val[BH_U];
 #pragma unroll
-          for (int u = 0; u < BIG_U; ++u) {
+          for (int u = 0; u < BH_U; ++u) {
             col[u] = nxt[u].x;
             val[u] = __int_as_float(nxt[u].y);
             mine[u] = i0 + u * BIG_THREADS + tid < cnt;
           }
 #pragma unroll
-          for (int u = 0; u < BIG_U; ++u) {
-            const int idx = i0 + BIG_THREADS * BIG_U + u * BIG_THREADS + tid;
+          for (int u = 0; u < BH_U; ++u) {
+            const int idx = i0 + BIG_THREADS * BH_U + u * BIG_THREADS + tid;
             nxt[u] = src[idx < cnt ? idx : 0];
           }
-          hash_accum_multi<BIG_U, false>(sh.tab, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
+          hash_accum_multi<BH_U, false>(sh.tab, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
         }
         __syncthreads();
         STAMP(3);

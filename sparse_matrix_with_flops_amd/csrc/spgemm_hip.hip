@@ -161,7 +161,7 @@ struct spgemm_handle {
   int2* spill = nullptr;
   int spill_blocks = 0;
   int bhCap = BH_CAP;
-  int h1sym = 24;                    // blocks per CU of the wave-per-row symbolic kernel (SPGEMM_H1SYM, experiments)
+  int h1sym = 32;                    // blocks per CU of the wave-per-row symbolic kernel (SPGEMM_H1SYM, experiments)
   spgemm_stats stats;
 };
 

@@ -1,9 +1,10 @@
 #!/bin/bash
-# experiment: occupancy sensitivity of the wave-per-row symbolic kernel (blocks per CU), 1M workload
-for B in 8 16 24 32; do
-  SPGEMM_H1SYM=$B timeout -k 10 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-verify > gpurun_out/exp_h1_$B.json 2> gpurun_out/err.txt || tail -5 gpurun_out/err.txt
+for V in "SPGEMM_U=2"; do
+  env $V timeout -k 10 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/exp_v.json 2> gpurun_out/err.txt || tail -5 gpurun_out/err.txt
+  env $V timeout -k 10 300 python bench.py --workload synth_256k_16 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/exp_w.json 2> gpurun_out/err.txt || tail -5 gpurun_out/err.txt
   python - <<PY
 import json
-d=json.load(open("gpurun_out/exp_h1_$B.json")); print("H1SYM=$B", d["ms_per_step"], d["roofline"]["all_kernels_avg_ms"]["k_sym_hash<1,1024>"])
+for f in ("gpurun_out/exp_v.json","gpurun_out/exp_w.json"):
+    d=json.load(open(f)); k=d["roofline"]["all_kernels_avg_ms"]; print("$V", d["ms_per_step"], d["parity"][:2], {x:k[x] for x in k if "hash" in x or "big" in x})
 PY
 done
