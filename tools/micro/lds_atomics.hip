@@ -6,7 +6,7 @@
 #include <vector>
 constexpr int SLOTS = 16384, ITERS = 2000, THREADS = 1024;
 enum Mode { CAS_RANDOM, CAS_LINEAR, CAS_8LANES_EXEC, CAS_8LANES_DUMMY, ADDF_RANDOM, READ_RANDOM, CAS64_RANDOM, ADDF_LINEAR, CAS_SAMEBANK,
-            ADDF_6LANES_EXEC, ADDF_1LANE_EXEC, ADDF_6LANES_ZERO, ADDU_RANDOM, ADDF_RTN_RANDOM, ADDF_CASLOOP, ADDF_32LANES_EXEC, NMODES };
+            ADDF_6LANES_EXEC, ADDF_1LANE_EXEC, ADDF_6LANES_ZERO, ADDU_RANDOM, ADDF_RTN_RANDOM, ADDF_CASLOOP, ADDF_32LANES_EXEC, OR_RANDOM, CAS_X4, READ_X4, CAS64_X4, OR_X4, ADDU_X4, NMODES };
 __global__ __launch_bounds__(THREADS) void k(int mode, const unsigned* __restrict__ rnd, unsigned long long* out, int* sink) {
   __shared__ __attribute__((aligned(16))) int tab[SLOTS * 2];
   __shared__ int dummy[THREADS];
@@ -35,6 +35,25 @@ __global__ __launch_bounds__(THREADS) void k(int mode, const unsigned* __restric
       case ADDF_6LANES_ZERO: atomicAdd(reinterpret_cast<float*>(lane < 6 ? &tab[a] : &dummy[tid]), lane < 6 ? 1.0f : 0.f); break;
       case ADDU_RANDOM: atomicAdd(reinterpret_cast<unsigned*>(&tab[a]), 1u); break;
       case ADDF_RTN_RANDOM: acc += (int)atomicAdd(reinterpret_cast<float*>(&tab[a]), 1.0f); break;
+      case OR_RANDOM: atomicOr(reinterpret_cast<unsigned*>(&tab[a]), 1u << (r & 31)); break;
+      case CAS_X4: { int t = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t += atomicCAS(&tab[(a + q * 4099) & (SLOTS - 1)], -1, it);
+        acc += t; } break;
+      case READ_X4: { int t = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t += tab[(a + q * 4099) & (SLOTS - 1)];
+        acc += t; } break;
+      case CAS64_X4: { int t = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t += (int)atomicCAS(reinterpret_cast<unsigned long long*>(&tab[2 * ((a + q * 4099) & (SLOTS - 1))]), ~0ull, (unsigned long long)it);
+        acc += t; } break;
+      case OR_X4: {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomicOr(reinterpret_cast<unsigned*>(&tab[(a + q * 4099) & (SLOTS - 1)]), 1u << (r & 31)); } break;
+      case ADDU_X4: {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomicAdd(reinterpret_cast<unsigned*>(&tab[(a + q * 4099) & (SLOTS - 1)]), 1u); } break;
       case ADDF_CASLOOP: { const int old = tab[a]; acc += atomicCAS(&tab[a], old, __float_as_int(__int_as_float(old) + 1.0f)); } break;
     }
   }
@@ -51,7 +70,7 @@ int main() {
   hipMalloc(&drnd, h.size() * 4); hipMalloc(&dout, blocks * 8); hipMalloc(&dsink, 4);
   hipMemcpy(drnd, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   const char* names[] = {"CAS32 random", "CAS32 linear (conflict-free)", "CAS32 random, 8 lanes by EXEC", "CAS32 8 lanes real + 56 private dummies",
-                         "ADD f32 random", "READ b32 random", "CAS64 random", "ADD f32 linear", "CAS32 all lanes same bank", "ADD f32 random, 6 lanes by EXEC", "ADD f32 random, 1 lane by EXEC", "ADD f32 6 lanes real + 58 dummies(+0)", "ADD u32 random", "ADD f32 rtn random", "f32 add by read+CAS32 (one try)", "ADD f32 random, 32 lanes by EXEC"};
+                         "ADD f32 random", "READ b32 random", "CAS64 random", "ADD f32 linear", "CAS32 all lanes same bank", "ADD f32 random, 6 lanes by EXEC", "ADD f32 random, 1 lane by EXEC", "ADD f32 6 lanes real + 58 dummies(+0)", "ADD u32 random", "ADD f32 rtn random", "f32 add by read+CAS32 (one try)", "ADD f32 random, 32 lanes by EXEC", "OR b32 random", "4 x CAS32 random per iteration", "4 x READ b32 random per iteration", "4 x CAS64 random per iteration", "4 x OR b32 per iteration", "4 x ADD u32 per iteration"};
   for (int m = 0; m < NMODES; ++m) {
     for (int rep = 0; rep < 2; ++rep) {
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
