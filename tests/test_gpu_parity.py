@@ -224,6 +224,19 @@ def test_big_rows_multi_window_and_rank_passes():
     assert_parity(hip_mul(A, B), want, what="big-rows")
 
 
+def test_big_rows_wider_than_one_symbolic_window():
+    """B with 2.5 M columns: the symbolic bitmap kernel covers 1 M columns per window, so rows above 4096 products
+    take three windows; the numeric side is the multi-pass LDS hash (one pass, parked passes, and the re-walk fallback
+    for a row with more hash classes than parking regions)."""
+    rng = np.random.default_rng(17)
+    k, n = 4000, 2500000
+    B = _rows_csr([np.sort(rng.choice(n, size=int(rng.integers(30, 90)), replace=False)) for _ in range(k)], n, 5)
+    A = _rows_csr([rng.choice(k, size=s, replace=False) for s in (120, 300, 0, 1100, 75, 3900)], k, 6)
+    want = po.sequential_spmm(A, B)
+    assert np.diff(want.rowPtr).max() > 16 * 10240        # more classes than BH_MAXCLS regions -> fallback path
+    assert_parity(hip_mul(A, B), want, what="wide-B big rows")
+
+
 def test_long_A_rows_and_empty_B_rows_in_staging():
     """A rows longer than one staging chunk (1024 / 512 / 64 entries) whose B rows are short or empty."""
     rng = np.random.default_rng(11)
