@@ -187,7 +187,8 @@ __device__ __forceinline__ int hash_insert_multi(int* keys, float* vals, int siz
       const bool fresh = pend[u] && old[u] == EMPTY_KEY;
       const bool fin = fresh || old[u] == col[u];
       claimed += fresh ? 1 : 0;
-      const unsigned nh = POW2 ? ((h[u] + 1u) & mask) : (h[u] + 1u == (unsigned)size ? 0u : h[u] + 1u);
+      // power-of-two tables: triangular steps (+1, +2, +3, ...) visit every slot once and break up probe clusters
+      const unsigned nh = POW2 ? ((h[u] + (unsigned)probe + 1u) & mask) : (h[u] + 1u == (unsigned)size ? 0u : h[u] + 1u);
       h[u] = (pend[u] && !fin) ? nh : h[u];
       pend[u] = pend[u] && !fin;
       more = more || pend[u];
@@ -263,7 +264,8 @@ __device__ __forceinline__ void hash_accum_multi(slot_t* tab, int size, int shif
       const bool same = pend[u] && slot_key(old[u]) == col[u];
       const bool fin = fresh || same;
       dup[u] = dup[u] || same;
-      const unsigned nh = POW2 ? ((h[u] + 1u) & mask) : (h[u] + 1u == (unsigned)size ? 0u : h[u] + 1u);
+      // power-of-two tables: triangular steps (+1, +2, +3, ...) visit every slot once and break up probe clusters
+      const unsigned nh = POW2 ? ((h[u] + (unsigned)probe + 1u) & mask) : (h[u] + 1u == (unsigned)size ? 0u : h[u] + 1u);
       h[u] = (pend[u] && !fin) ? nh : h[u];
       pend[u] = pend[u] && !fin;
       more = more || pend[u];
