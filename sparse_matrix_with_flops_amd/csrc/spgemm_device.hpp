@@ -241,13 +241,15 @@ template <int U, bool POW2 = true>
 __device__ __forceinline__ void hash_accum_multi(slot_t* tab, int size, int shift, const bool (&act)[U],
                                                  const int (&col)[U], const float (&val)[U], slot_t* dummy, int* err) {
   const unsigned mask = (unsigned)size - 1u;
-  unsigned h[U];
+  unsigned h[U], step[U];
   bool pend[U], dup[U];
   slot_t mine[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const unsigned hv = (unsigned)col[u] * 2654435761u;
     h[u] = POW2 ? hv >> shift : __umulhi(hv, (unsigned)size);
+    // tables of 1024*k slots (k <= 17): double hashing with a prime step > 17, coprime with every such size
+    step[u] = POW2 ? 0u : (unsigned)((0x2f2b29251f1d1713ull >> (((hv >> 7) & 7u) * 8u)) & 0xffu);
     pend[u] = act[u];
     dup[u] = false;
     mine[u] = make_slot(col[u], val[u]);
@@ -265,7 +267,7 @@ __device__ __forceinline__ void hash_accum_multi(slot_t* tab, int size, int shif
       const bool fin = fresh || same;
       dup[u] = dup[u] || same;
       // power-of-two tables: triangular steps (+1, +2, +3, ...) visit every slot once and break up probe clusters
-      const unsigned nh = POW2 ? ((h[u] + (unsigned)probe + 1u) & mask) : (h[u] + 1u == (unsigned)size ? 0u : h[u] + 1u);
+      const unsigned nh = POW2 ? ((h[u] + (unsigned)probe + 1u) & mask) : (h[u] + step[u] >= (unsigned)size ? h[u] + step[u] - (unsigned)size : h[u] + step[u]);
       h[u] = (pend[u] && !fin) ? nh : h[u];
       pend[u] = pend[u] && !fin;
       more = more || pend[u];
