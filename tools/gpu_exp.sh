@@ -1,6 +1,8 @@
 #!/bin/bash
-# parity tests under the tuning knobs users can set
-timeout -k 10 500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/t_default.log 2>&1; echo "default exit=$?"; tail -2 gpurun_out/t_default.log
-for V in "SPGEMM_U=4" "SPGEMM_U=8" "SPGEMM_CONCURRENT=1" "SPGEMM_BHCAP=12800"; do
-  env $V timeout -k 10 500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/t_var.log 2>&1; echo "$V exit=$?"; tail -1 gpurun_out/t_var.log
+for V in "SPGEMM_BHCAP=10240" "SPGEMM_BHCAP=11264" "SPGEMM_BHCAP=12800"; do
+  env $V timeout -k 10 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-verify > gpurun_out/exp_v.json 2> gpurun_out/err.txt || tail -5 gpurun_out/err.txt
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/exp_v.json")); k=d["roofline"]["all_kernels_avg_ms"]; print("$V", d["ms_per_step"], {x:k[x] for x in k if "bighash" in x})
+PY
 done
