@@ -78,6 +78,9 @@ constexpr int ERRF_COUNT_MISMATCH = 2;
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
 
+// lane mask of a predicate, straight from the compare (HIP's __ballot(int) goes through a 0/1 VGPR and back)
+__device__ __forceinline__ unsigned long long ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+
 // number of set bits of `mask` strictly below this lane
 __device__ __forceinline__ int mask_rank(unsigned long long mask) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
@@ -163,44 +166,45 @@ __device__ __forceinline__ int hash_insert(int* keys, int size, int shift, int c
 // vals == nullptr: symbolic (count only).  `dummy` = one private int per lane.  Returns the slots this lane claimed.
 // POW2: size is a power of two (slot = top bits of the multiplicative hash); otherwise any size
 // (slot = mulhi(hash, size)), which lets the big-row kernel use every byte of LDS it can get.
+// The loop-carried state of the multi-insert loops is integers only: the byte offset of the slot a lane probes next,
+// with the lane's private dummy word standing for "done".  (Carried bools live in VGPRs as 0/1 and cost two VALU
+// instructions each per round to turn back into lane masks; these kernels are VALU-bound.)  Conditions used inside
+// one round stay lane masks in SGPRs and combine on the scalar unit.
+// Returns the number of new keys of the whole WAVE (uniform).
 template <int U, bool POW2 = true>
-__device__ __forceinline__ int hash_insert_multi(int* keys, float* vals, int size, int shift, const bool (&act)[U],
-                                                 const int (&col)[U], const float (&val)[U], int* dummy, int* err) {
-  const unsigned mask = (unsigned)size - 1u;
-  unsigned h[U];
-  bool pend[U];
+__device__ __forceinline__ int hash_insert_multi(int* keys, int size, int shift, const bool (&act)[U],
+                                                 const int (&col)[U], int* dummy, int* err) {
+  char* const base = reinterpret_cast<char*>(keys);
+  const int dumB = (int)(reinterpret_cast<char*>(dummy) - base);
+  const int maskB = size * 4 - 1;
+  int hB[U];
   int claimed = 0;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const unsigned hv = (unsigned)col[u] * 2654435761u;
-    h[u] = POW2 ? hv >> shift : __umulhi(hv, (unsigned)size);
-    pend[u] = act[u];
+    const unsigned h = POW2 ? hv >> shift : __umulhi(hv, (unsigned)size);
+    hB[u] = act[u] ? (int)(h * 4u) : dumB;
   }
   bool done = false;
   for (int probe = 0; probe < size && !done; ++probe) {
     int old[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) old[u] = atomicCAS(pend[u] ? &keys[h[u]] : dummy, EMPTY_KEY, col[u]);
+    for (int u = 0; u < U; ++u) old[u] = atomicCAS(reinterpret_cast<int*>(base + hB[u]), EMPTY_KEY, col[u]);
     bool more = false;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool fresh = pend[u] && old[u] == EMPTY_KEY;
-      const bool fin = fresh || old[u] == col[u];
-      claimed += fresh ? 1 : 0;
+      const bool pend = hB[u] != dumB;
+      const bool fresh = pend && old[u] == EMPTY_KEY;
+      const bool adv = pend && !fresh && old[u] != col[u];
+      claimed += __popcll(ballot64(fresh));
       // power-of-two tables: triangular steps (+1, +2, +3, ...) visit every slot once and break up probe clusters
-      const unsigned nh = POW2 ? ((h[u] + (unsigned)probe + 1u) & mask) : (h[u] + 1u == (unsigned)size ? 0u : h[u] + 1u);
-      h[u] = (pend[u] && !fin) ? nh : h[u];
-      pend[u] = pend[u] && !fin;
-      more = more || pend[u];
+      const int nh = POW2 ? ((hB[u] + (probe + 1) * 4) & maskB) : (hB[u] + 4 == size * 4 ? 0 : hB[u] + 4);
+      hB[u] = adv ? nh : dumB;
+      more = more || adv;
     }
-    done = !__any(more);
+    done = ballot64(more) == 0ull;
   }
   if (!done) atomicOr(err, ERRF_TABLE_FULL);
-  if (vals) {
-    float* fdummy = reinterpret_cast<float*>(dummy);
-#pragma unroll
-    for (int u = 0; u < U; ++u) atomicAdd(act[u] ? &vals[h[u]] : fdummy, act[u] ? val[u] : 0.f);
-  }
   return claimed;
 }
 
@@ -240,44 +244,45 @@ __device__ __forceinline__ void hash_accum(slot_t* tab, int size, int shift, int
 template <int U, bool POW2 = true>
 __device__ __forceinline__ void hash_accum_multi(slot_t* tab, int size, int shift, const bool (&act)[U],
                                                  const int (&col)[U], const float (&val)[U], slot_t* dummy, int* err) {
-  const unsigned mask = (unsigned)size - 1u;
-  unsigned h[U], step[U];
-  bool pend[U], dup[U];
+  char* const base = reinterpret_cast<char*>(tab);
+  const int dumB = (int)(reinterpret_cast<char*>(dummy) - base);
+  const int maskB = size * 8 - 1, sizeB = size * 8;
+  int hB[U], stepB[U], dupB[U];                   // byte offsets; dumB = "done" / "no repeated column"
   slot_t mine[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const unsigned hv = (unsigned)col[u] * 2654435761u;
-    h[u] = POW2 ? hv >> shift : __umulhi(hv, (unsigned)size);
+    const unsigned h = POW2 ? hv >> shift : __umulhi(hv, (unsigned)size);
     // tables of 1024*k slots (k <= 17): double hashing with a prime step > 17, coprime with every such size
-    step[u] = POW2 ? 0u : (unsigned)((0x2f2b29251f1d1713ull >> (((hv >> 7) & 7u) * 8u)) & 0xffu);
-    pend[u] = act[u];
-    dup[u] = false;
+    stepB[u] = POW2 ? 0 : (int)((0x2f2b29251f1d1713ull >> (((hv >> 7) & 7u) * 8u)) & 0xffu) * 8;
+    hB[u] = act[u] ? (int)(h * 8u) : dumB;
+    dupB[u] = dumB;
     mine[u] = make_slot(col[u], val[u]);
   }
   bool done = false;
   for (int probe = 0; probe < size && !done; ++probe) {
     slot_t old[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) old[u] = atomicCAS(pend[u] ? &tab[h[u]] : dummy, EMPTY_SLOT, mine[u]);
+    for (int u = 0; u < U; ++u) old[u] = atomicCAS(reinterpret_cast<slot_t*>(base + hB[u]), EMPTY_SLOT, mine[u]);
     bool more = false;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool fresh = pend[u] && old[u] == EMPTY_SLOT;
-      const bool same = pend[u] && slot_key(old[u]) == col[u];
-      const bool fin = fresh || same;
-      dup[u] = dup[u] || same;
-      // power-of-two tables: triangular steps (+1, +2, +3, ...) visit every slot once and break up probe clusters
-      const unsigned nh = POW2 ? ((h[u] + (unsigned)probe + 1u) & mask) : (h[u] + step[u] >= (unsigned)size ? h[u] + step[u] - (unsigned)size : h[u] + step[u]);
-      h[u] = (pend[u] && !fin) ? nh : h[u];
-      pend[u] = pend[u] && !fin;
-      more = more || pend[u];
+      const bool pend = hB[u] != dumB;
+      const bool same = pend && slot_key(old[u]) == col[u];
+      const bool adv = pend && !same && old[u] != EMPTY_SLOT;
+      dupB[u] = same ? hB[u] : dupB[u];
+      int nh;
+      if (POW2) nh = (hB[u] + (probe + 1) * 8) & maskB;     // triangular steps
+      else { nh = hB[u] + stepB[u]; nh = nh >= sizeB ? nh - sizeB : nh; }
+      hB[u] = adv ? nh : dumB;
+      more = more || adv;
     }
-    done = !__any(more);
+    done = ballot64(more) == 0ull;
   }
   if (!done) atomicOr(err, ERRF_TABLE_FULL);
 #pragma unroll
   for (int u = 0; u < U; ++u)
-    if (dup[u]) atomicAdd(slot_val_ptr(tab, h[u]), val[u]);
+    if (dupB[u] != dumB) atomicAdd(reinterpret_cast<float*>(base + dupB[u] + 4), val[u]);
 }
 
 // float add into an LDS word by read + 32-bit CAS (retry on interference): ~2 cheap LDS ops instead of a
@@ -302,7 +307,7 @@ __device__ __forceinline__ void lds_fadd_multi(float* acc, const int (&idx)[U], 
       old[u] = got[u];
       more = more || pend[u];
     }
-    if (!__any(more)) break;
+    if (ballot64(more) == 0ull) break;
   }
 }
 
@@ -332,7 +337,7 @@ __device__ __forceinline__ void emit_claimed(const slot_t* tab, int base, int pe
 #pragma unroll
   for (int sidx = 0; sidx < MAXSTEPS; ++sidx) {
     sl[sidx] = sidx * WAVE < per ? tab[base + sidx * WAVE + lane] : EMPTY_SLOT;
-    cnt += __popcll(__ballot(slot_key(sl[sidx]) != EMPTY_KEY));
+    cnt += __popcll(ballot64(slot_key(sl[sidx]) != EMPTY_KEY));
   }
   int pos = 0;
   if (lane == 0) pos = atomicAdd(emitted, cnt);
@@ -340,7 +345,7 @@ __device__ __forceinline__ void emit_claimed(const slot_t* tab, int base, int pe
 #pragma unroll
   for (int sidx = 0; sidx < MAXSTEPS; ++sidx) {
     const bool occ = slot_key(sl[sidx]) != EMPTY_KEY;
-    const unsigned long long mk = __ballot(occ);
+    const unsigned long long mk = ballot64(occ);
     if (occ) {
       const int o = pos + mask_rank(mk);
       if (o < outHi) { JC[o] = slot_key(sl[sidx]); C[o] = slot_val(sl[sidx]); }
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(K1_THREADS) void k_row_flops(
     for (int t = 0; t < FL_SHORT; ++t) if (js[t] >= 0) f += (unsigned)(IB[js[t] + 1] - IB[js[t]]);
   }
   // long rows: the wave takes them one by one
-  unsigned long long longMask = __ballot(re - rs > FL_SHORT);
+  unsigned long long longMask = ballot64(re - rs > FL_SHORT);
   while (longMask) {
     const int src = __ffsll((long long)longMask) - 1;
     longMask &= longMask - 1;
@@ -399,12 +404,12 @@ __global__ __launch_bounds__(K1_THREADS) void k_row_flops(
   }
 #pragma unroll
   for (int q = 0; q < SLOT_BIG0; ++q) {
-    const unsigned long long mk = __ballot(b == q);
+    const unsigned long long mk = ballot64(b == q);
     if (lane == 0 && mk) atomicAdd(&hist[q], __popcll(mk));
   }
-  if (__ballot(b >= SLOT_BIG0)) {                    // big rows are rare: most waves skip their size classes
+  if (ballot64(b >= SLOT_BIG0)) {                    // big rows are rare: most waves skip their size classes
     for (int q = SLOT_BIG0; q < NSLOTS; ++q) {
-      const unsigned long long mk = __ballot(b == q);
+      const unsigned long long mk = ballot64(b == q);
       if (lane == 0 && mk) atomicAdd(&hist[q], __popcll(mk));
     }
   }
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(K1_THREADS) void k_scatter_rows(int m, const unsign
   int myrank = 0;
 #pragma unroll
   for (int q = 0; q < NSLOTS; ++q) {
-    const unsigned long long mk = __ballot(b == q);
+    const unsigned long long mk = ballot64(b == q);
     if (b == q) myrank = mask_rank(mk);
     if (lane == 0) wcnt[w][q] = __popcll(mk);
   }
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(256) void k_num_small(const int* __restrict__ binPt
     for (int i0 = 0; i0 < size; i0 += G) {
       const slot_t sv = tab[g][i0 + gl];
       const bool occ = live && slot_key(sv) != EMPTY_KEY;
-      const unsigned long long mk = __ballot(occ);
+      const unsigned long long mk = ballot64(occ);
       const int shiftg = lane_id() - gl;
       const unsigned long long gm = (G == 64) ? mk : ((mk >> shiftg) & ((1ull << G) - 1ull));
       const int rank = __popcll(gm & ((1ull << gl) - 1ull));
@@ -749,7 +754,7 @@ __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr,
     for (int i0 = 0; i0 < size; i0 += 16) {
       const slot_t sv = tab[g][i0 + gl];
       const bool occ = live && slot_key(sv) != EMPTY_KEY;
-      const unsigned long long mk = __ballot(occ);
+      const unsigned long long mk = ballot64(occ);
       const unsigned gm = (unsigned)(mk >> (lane_id() - gl)) & 0xffffu;
       const int rank = __popc(gm & ((1u << gl) - 1u));
       if (occ) { JC[off + written + rank] = slot_key(sv); C[off + written + rank] = slot_val(sv); }
@@ -834,22 +839,24 @@ __device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, in
         p[u] = p0 + lane;
         int grp = 0;
         if (NW > 1) {
-          const int g0 = __popcll(__ballot(bv <= p0));
-          const int g1 = __popcll(__ballot(bv <= p0 + (WAVE - 1)));
+          const int g0 = __popcll(ballot64(bv <= p0));
+          const int g1 = __popcll(ballot64(bv <= p0 + (WAVE - 1)));
           grp = g0;
           if (g0 != g1) {                            // the round straddles a group boundary (about 1 in 16)
             for (int i = g0; i < g1; ++i) grp += st.incl[i * WAVE + WAVE - 1] <= p[u] ? 1 : 0;
           }
         }
-        e[u] = grp * WAVE;
+        e[u] = grp * WAVE * 4;                       // byte offset into the staged arrays
       }
-      // first entry with incl > p inside the group, all U searches in lock step
+      // first entry with incl > p inside the group, all U searches in lock step.  Offsets stay in bytes, so a step
+      // is add + ds_read(offset) + compare + select (the kernels are VALU-bound: instruction count is time)
+      const char* inclB = reinterpret_cast<const char*>(st.incl);
 #pragma unroll
       for (int sft = WAVE / 2; sft >= 1; sft >>= 1) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int c = e[u] + sft;
-          e[u] = st.incl[c - 1] <= p[u] ? c : e[u];
+          const int c = e[u] + sft * 4;
+          e[u] = *reinterpret_cast<const int*>(inclB + c - 4) <= p[u] ? c : e[u];
         }
       }
       int col[U];
@@ -863,9 +870,9 @@ __device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, in
       for (int u = 0; u < U; ++u) {                // straight-line: lanes past the end re-read product 0
         act[u] = p[u] < T;
         const int ee = act[u] ? e[u] : 0;
-        const int jb = st.off[ee] + (act[u] ? p[u] : 0);
+        const int jb = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(st.off) + ee) + (act[u] ? p[u] : 0);
         col[u] = JB[jb];
-        val[u] = NEED_VAL ? st.aval[ee] * VB[jb] : 0.f;
+        val[u] = NEED_VAL ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(st.aval) + ee) * VB[jb] : 0.f;
       }
 #ifdef SMF_STAMPS
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1010,9 +1017,9 @@ __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ 
     int mine = 0;
     for_each_product<NW, U, false>(st, cur.as, cur.ae, JA, nullptr, IB, JB, nullptr,
                                    [&](const bool (&act)[U], const int (&col)[U], const float (&val)[U]) {
-      mine += hash_insert_multi<U>(keys, nullptr, size, shift, act, col, val, reinterpret_cast<int*>(&st.dummy[threadIdx.x]), err);
+      mine += hash_insert_multi<U>(keys, size, shift, act, col, reinterpret_cast<int*>(&st.dummy[threadIdx.x]), err);
     }, pc);
-    const int ws = wave_sum(mine);
+    const int ws = __builtin_amdgcn_readfirstlane(mine);   // hash_insert_multi counts per wave
     if (NW == 1) {
       if (lane == 0) IC[cur.row] = ws;
     } else {
@@ -1090,7 +1097,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
       for (int i0 = 0; i0 < per; i0 += WAVE) {
         const slot_t sv = tab[i0 + lane];
         const bool occ = slot_key(sv) != EMPTY_KEY;
-        const unsigned long long mk = __ballot(occ);
+        const unsigned long long mk = ballot64(occ);
         if (occ) { const int o = pos + mask_rank(mk); JC[o] = slot_key(sv); C[o] = slot_val(sv); }
         pos += __popcll(mk);
       }
@@ -1400,7 +1407,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
               unsigned long long mk[BH_U];
               int total = 0;
 #pragma unroll
-              for (int u = 0; u < BH_U; ++u) { mk[u] = __ballot(act[u] && cls[u] == c); total += __popcll(mk[u]); }
+              for (int u = 0; u < BH_U; ++u) { mk[u] = ballot64(act[u] && cls[u] == c); total += __popcll(mk[u]); }
               if (total) {                             // wave-uniform
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&sh.spillCnt[c], total);
@@ -1662,7 +1669,7 @@ __global__ __launch_bounds__(256) void k_rmcl_compact(int m, const int* __restri
       const int p = p0 + gl;
       const float v = p < e ? C[p] : 0.f;
       const bool keep = p < e && v >= th;
-      const unsigned long long mk = __ballot(keep);
+      const unsigned long long mk = ballot64(keep);
       const unsigned gm = (unsigned)(mk >> (lane - gl)) & 0xffffu;
       if (keep) { const int o = out + __popc(gm & ((1u << gl) - 1u)); JN[o] = JC[p]; CN[o] = v / ks; }
       out += __popc(gm);
@@ -1678,7 +1685,7 @@ __global__ void k_selftest(const int* __restrict__ in, int* __restrict__ bad) {
   buf[lane] = v;
   const int a = wave_incl_add(v);
   const int mx = wave_incl_max(v & 0xffff);
-  const unsigned long long mk = __ballot(v & 1);
+  const unsigned long long mk = ballot64(v & 1);
   const int rk = mask_rank(mk);
   __syncthreads();
   int ea = 0, em = 0, er = 0;
