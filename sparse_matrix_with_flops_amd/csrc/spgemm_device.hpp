@@ -186,7 +186,8 @@ __device__ __forceinline__ int hash_insert_multi(int* keys, int size, int shift,
     hB[u] = act[u] ? (int)(h * 4u) : dumB;
   }
   bool done = false;
-  for (int probe = 0; probe < size && !done; ++probe) {
+  int probe = 0;
+  do {                                              // at least one round: nothing between the gathers and their use
     int old[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) old[u] = atomicCAS(reinterpret_cast<int*>(base + hB[u]), EMPTY_KEY, col[u]);
@@ -203,7 +204,7 @@ __device__ __forceinline__ int hash_insert_multi(int* keys, int size, int shift,
       more = more || adv;
     }
     done = ballot64(more) == 0ull;
-  }
+  } while (++probe < size && !done);
   if (!done) atomicOr(err, ERRF_TABLE_FULL);
   return claimed;
 }
@@ -260,7 +261,8 @@ __device__ __forceinline__ void hash_accum_multi(slot_t* tab, int size, int shif
     mine[u] = make_slot(col[u], val[u]);
   }
   bool done = false;
-  for (int probe = 0; probe < size && !done; ++probe) {
+  int probe = 0;
+  do {                                              // at least one round: the col and value gathers stay together
     slot_t old[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) old[u] = atomicCAS(reinterpret_cast<slot_t*>(base + hB[u]), EMPTY_SLOT, mine[u]);
@@ -278,7 +280,7 @@ __device__ __forceinline__ void hash_accum_multi(slot_t* tab, int size, int shif
       more = more || adv;
     }
     done = ballot64(more) == 0ull;
-  }
+  } while (++probe < size && !done);
   if (!done) atomicOr(err, ERRF_TABLE_FULL);
 #pragma unroll
   for (int u = 0; u < U; ++u)
@@ -866,14 +868,19 @@ __device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, in
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       STAMP(5);                                   // search done
 #endif
+      float av[U], vb[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {                // straight-line: lanes past the end re-read product 0
         act[u] = p[u] < T;
         const int ee = act[u] ? e[u] : 0;
         const int jb = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(st.off) + ee) + (act[u] ? p[u] : 0);
         col[u] = JB[jb];
-        val[u] = NEED_VAL ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(st.aval) + ee) * VB[jb] : 0.f;
+        vb[u] = NEED_VAL ? VB[jb] : 0.f;
+        av[u] = NEED_VAL ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(st.aval) + ee) : 0.f;
       }
+      __builtin_amdgcn_sched_barrier(0);           // all 2U gathers are issued before the first of them is waited for
+#pragma unroll
+      for (int u = 0; u < U; ++u) val[u] = av[u] * vb[u];
 #ifdef SMF_STAMPS
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       STAMP(6);                                   // gather landed
