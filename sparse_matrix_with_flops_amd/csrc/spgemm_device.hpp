@@ -655,7 +655,7 @@ __device__ __forceinline__ void g16_walk(G16Stage& st, int gl, int as, int ae, c
     for (int r0 = 0; r0 * 16 < T; r0 += U) {
       int p[U], e[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) { p[u] = (r0 + u) * 16 + gl; e[u] = 0; }
+      for (int u = 0; u < U; ++u) { p[u] = min((r0 + u) * 16 + gl, T - 1); e[u] = 0; }   // past the end: shadow the last product
 #pragma unroll
       for (int sft = 8; sft >= 1; sft >>= 1) {
 #pragma unroll
@@ -665,19 +665,19 @@ __device__ __forceinline__ void g16_walk(G16Stage& st, int gl, int as, int ae, c
         }
       }
       int col[U];
-      float val[U];
+      float val[U], av[U], vb[U];
       bool act[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        act[u] = p[u] < T;
-        col[u] = 0;
-        val[u] = 0.f;
-        if (act[u]) {
-          const int jb = st.off[e[u]] + p[u];
-          col[u] = JB[jb];
-          if (NEED_VAL) val[u] = st.aval[e[u]] * VB[jb];
-        }
+      for (int u = 0; u < U; ++u) {                // straight-line, no branches around the gathers
+        act[u] = (r0 + u) * 16 + gl < T;
+        const int jb = st.off[e[u]] + p[u];
+        col[u] = JB[jb];
+        vb[u] = NEED_VAL ? VB[jb] : 0.f;
+        av[u] = NEED_VAL ? st.aval[e[u]] : 0.f;
       }
+      __builtin_amdgcn_sched_barrier(0);           // all gathers issued before the first wait
+#pragma unroll
+      for (int u = 0; u < U; ++u) val[u] = av[u] * vb[u];
 #pragma unroll
       for (int u = 0; u < U; ++u) f(act[u], col[u], val[u]);
     }
@@ -835,14 +835,18 @@ __device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, in
       int tnext = t + 1;
       if (NW > 1) { tnext = 0; if (lane == 0) tnext = atomicAdd(&st.trip, 1); }
       int p[U], e[U];
+      bool act[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int p0 = (t * U + u) * WAVE;
-        p[u] = p0 + lane;
+        act[u] = p0 + lane < T;
+        p[u] = min(p0 + lane, T - 1);                // lanes past the end shadow the last product: valid, nearby reads
         int grp = 0;
         if (NW > 1) {
-          const int g0 = __popcll(ballot64(bv <= p0));
-          const int g1 = __popcll(ballot64(bv <= p0 + (WAVE - 1)));
+          // (clamped like p[u]: a round past the end of the chunk must land in the group of the last product,
+          // whose entry is real -- the padding entries behind the row have no B row to read from)
+          const int g0 = __popcll(ballot64(bv <= min(p0, T - 1)));
+          const int g1 = __popcll(ballot64(bv <= min(p0 + (WAVE - 1), T - 1)));
           grp = g0;
           if (g0 != g1) {                            // the round straddles a group boundary (about 1 in 16)
             for (int i = g0; i < g1; ++i) grp += st.incl[i * WAVE + WAVE - 1] <= p[u] ? 1 : 0;
@@ -863,20 +867,17 @@ __device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, in
       }
       int col[U];
       float val[U];
-      bool act[U];
 #ifdef SMF_STAMPS
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       STAMP(5);                                   // search done
 #endif
       float av[U], vb[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {                // straight-line: lanes past the end re-read product 0
-        act[u] = p[u] < T;
-        const int ee = act[u] ? e[u] : 0;
-        const int jb = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(st.off) + ee) + (act[u] ? p[u] : 0);
+      for (int u = 0; u < U; ++u) {                // straight-line, no branches around the gathers
+        const int jb = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(st.off) + e[u]) + p[u];
         col[u] = JB[jb];
         vb[u] = NEED_VAL ? VB[jb] : 0.f;
-        av[u] = NEED_VAL ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(st.aval) + ee) : 0.f;
+        av[u] = NEED_VAL ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(st.aval) + e[u]) : 0.f;
       }
       __builtin_amdgcn_sched_barrier(0);           // all 2U gathers are issued before the first of them is waited for
 #pragma unroll
