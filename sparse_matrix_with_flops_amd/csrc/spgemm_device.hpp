@@ -831,7 +831,7 @@ __device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, in
     // ---- trips of U consecutive rounds (64*U products).  The first NW trips are dealt out, the rest are claimed
     // from an LDS counter as waves finish: probe chains make trip times uneven and the chunk ends on a barrier
     const int ntrips = (nrounds + U - 1) / U;
-    for (int t = w; t < ntrips;) {
+    for (int t = __builtin_amdgcn_readfirstlane(w); t < ntrips;) {   // t is wave-uniform: keep its arithmetic scalar
       int tnext = t + 1;
       if (NW > 1) { tnext = 0; if (lane == 0) tnext = atomicAdd(&st.trip, 1); }
       int p[U], e[U];
