@@ -343,15 +343,18 @@ __device__ __forceinline__ void emit_claimed(const slot_t* tab, int base, int pe
   }
   int pos = 0;
   if (lane == 0) pos = atomicAdd(emitted, cnt);
-  pos = outLo + __builtin_amdgcn_readfirstlane(pos);
+  pos = __builtin_amdgcn_readfirstlane(pos);
+  // positions relative to the row: one small 32-bit offset serves both output arrays (uniform base + offset stores)
+  int* const JCrow = JC + outLo;
+  float* const Crow = C + outLo;
+  const unsigned lim = (unsigned)(outHi - outLo);
 #pragma unroll
   for (int sidx = 0; sidx < MAXSTEPS; ++sidx) {
     const bool occ = slot_key(sl[sidx]) != EMPTY_KEY;
     const unsigned long long mk = ballot64(occ);
-    if (occ) {
-      const int o = pos + mask_rank(mk);
-      if (o < outHi) { JC[o] = slot_key(sl[sidx]); C[o] = slot_val(sl[sidx]); }
-    }
+    const unsigned o = (unsigned)(pos + mask_rank(mk));
+    __builtin_assume(o < (1u << 24));
+    if (occ && o < lim) { JCrow[o] = slot_key(sl[sidx]); Crow[o] = slot_val(sl[sidx]); }
     pos += __popcll(mk);
   }
 }
@@ -1101,15 +1104,19 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
     const int per = size / NW;
     const int lane = lane_id(), w = tid >> 6;
     if (NW == 1) {
-      int pos = off;
+      int pos = 0;                                    // relative to the row: small 32-bit offsets for both stores
+      int* const JCrow = JC + off;
+      float* const Crow = C + off;
       for (int i0 = 0; i0 < per; i0 += WAVE) {
         const slot_t sv = tab[i0 + lane];
         const bool occ = slot_key(sv) != EMPTY_KEY;
         const unsigned long long mk = ballot64(occ);
-        if (occ) { const int o = pos + mask_rank(mk); JC[o] = slot_key(sv); C[o] = slot_val(sv); }
+        const unsigned o = (unsigned)(pos + mask_rank(mk));
+        __builtin_assume(o < (1u << 24));
+        if (occ && o < (unsigned)want) { JCrow[o] = slot_key(sv); Crow[o] = slot_val(sv); }
         pos += __popcll(mk);
       }
-      if (tid == 0 && pos - off != want) atomicOr(err, ERRF_COUNT_MISMATCH);
+      if (tid == 0 && pos != want) atomicOr(err, ERRF_COUNT_MISMATCH);
       __syncthreads();
     } else {
       emit_claimed<TBL / NW / WAVE>(tab, w * per, per, &emitted, off, off + want, JC, C);
