@@ -353,7 +353,6 @@ __device__ __forceinline__ void emit_claimed(const slot_t* tab, int base, int pe
     const bool occ = slot_key(sl[sidx]) != EMPTY_KEY;
     const unsigned long long mk = ballot64(occ);
     const unsigned o = (unsigned)(pos + mask_rank(mk));
-    __builtin_assume(o < (1u << 24));
     if (occ && o < lim) { JCrow[o] = slot_key(sl[sidx]); Crow[o] = slot_val(sl[sidx]); }
     pos += __popcll(mk);
   }
@@ -1112,7 +1111,6 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
         const bool occ = slot_key(sv) != EMPTY_KEY;
         const unsigned long long mk = ballot64(occ);
         const unsigned o = (unsigned)(pos + mask_rank(mk));
-        __builtin_assume(o < (1u << 24));
         if (occ && o < (unsigned)want) { JCrow[o] = slot_key(sv); Crow[o] = slot_val(sv); }
         pos += __popcll(mk);
       }
