@@ -1153,7 +1153,7 @@ constexpr int BH_CAP = 10240;                  // distinct columns per hash pass
                                                // best of 8704/10240/12800 once later passes stream parked products)
 constexpr int BH_CAP_MAX = 12800;              // SPGEMM_BHCAP may raise the cap to this (load 0.74)
 constexpr int BH_SPILL = 1 << 18;              // (col,val) pairs a multi-pass row may park in HBM per block (2 MB)
-constexpr int BH_MAXCLS = 16;                  // hash classes (passes) with their own parking region
+constexpr int BH_MAXCLS = 32;                  // hash classes (passes) with their own parking region
 
 struct BigSymShared {
   unsigned bitmap[SYM_WORDS];
@@ -1178,6 +1178,7 @@ struct BigHashShared {
   int red[BIG_NW];
   int spillCnt[BH_MAXCLS];
   int emitted;
+  int ovf;                       // a parking region overflowed: redo the row without parking
 };
 
 __device__ __forceinline__ int block_sum_16(int v, int* red) {
@@ -1374,7 +1375,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
                                                              const int* __restrict__ IC, int* __restrict__ JC,
                                                              float* __restrict__ C, int* __restrict__ err,
                                                              int* __restrict__ qctr, const int* __restrict__ rowFlops,
-                                                             int2* __restrict__ spill, int spillCap, int bhCap) {
+                                                             int2* __restrict__ spill, int spillCap, int bhCap, int marginPct) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   BigHashShared& sh = *reinterpret_cast<BigHashShared*>(smem_raw);
   const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
@@ -1389,19 +1390,23 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
     const int outEnd = IC[row + 1];
     const int want = outEnd - outBase;
     const unsigned npass = (unsigned)((want + bhCap - 1) / bhCap);
-    // class c >= 1 parks in its own region of `stride` pairs (no class can hold more than the row's products)
-    const int stride = rowFlops[row];
-    const bool useSpill = npass > 1 && npass <= (unsigned)BH_MAXCLS && park != nullptr &&
+    // class c >= 1 parks in its own region of `stride` pairs: the expected class size (the classes are a hash of the
+    // column, so products/npass) plus a margin.  A class that outgrows its region raises sh.ovf and the row is redone
+    // the slow way (one walk per pass) -- rare, and never wrong.
+    const int flops = rowFlops[row];
+    const int stride = (int)min((long long)flops, (long long)flops * marginPct / (100ll * (long long)npass) + 256ll);
+    const bool canSpill = npass > 1 && npass <= (unsigned)BH_MAXCLS && park != nullptr &&
                           (long long)(npass - 1) * stride <= (long long)spillCap;
     // any multiple of 1024 slots (64 per wave-step): twice the distinct columns of a pass when that fits
     const int perPass = (want + (int)npass - 1) / (int)npass;
     const int size = min(BH_SLOTS, max(BIG_THREADS, (2 * perPass + BIG_THREADS - 1) / BIG_THREADS * BIG_THREADS));
     const int shift = 0;
     const int per = size / BIG_NW;
-    for (unsigned pass = 0; pass < npass; ++pass) {
+    bool useSpill = canSpill;
+    for (unsigned pass = 0; pass < npass;) {
       clear_slots(sh.tab, size, tid, BIG_THREADS);
       if (pass == 0 && tid < BH_MAXCLS) sh.spillCnt[tid] = 0;
-      if (pass == 0 && tid == 0) sh.emitted = 0;
+      if (pass == 0 && tid == 0) { sh.emitted = 0; sh.ovf = 0; }
       __syncthreads();
       STAMP(1);
       if (pass == 0 || !useSpill) {
@@ -1425,17 +1430,26 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&sh.spillCnt[c], total);
                 base = __builtin_amdgcn_readfirstlane(base);
-                int2* const dst = park + (size_t)(c - 1) * (size_t)stride;
+                if (base + total > stride) {           // wave-uniform: region full, the row will be redone
+                  if (lane == 0) sh.ovf = 1;
+                } else {
+                  int2* const dst = park + (size_t)(c - 1) * (size_t)stride;
 #pragma unroll
-                for (int u = 0; u < BH_U; ++u) {
-                  if (act[u] && cls[u] == c) dst[base + mask_rank(mk[u])] = make_int2(col[u], __float_as_int(val[u]));
-                  base += __popcll(mk[u]);
+                  for (int u = 0; u < BH_U; ++u) {
+                    if (act[u] && cls[u] == c) dst[base + mask_rank(mk[u])] = make_int2(col[u], __float_as_int(val[u]));
+                    base += __popcll(mk[u]);
+                  }
                 }
               }
             }
           }
         } STAMP_ARGS);
         STAMP(2);
+        if (pass == 0 && useSpill && sh.ovf) {        // block-uniform (read after the walk's closing barrier)
+          __syncthreads();                             // everyone has seen the flag before it is reset
+          useSpill = false;
+          continue;                                    // pass 0 again, without parking: table and counters are reset
+        }
       } else {
         // stream this class's parked pairs; the next batch is in flight while the current one is inserted
         const int cnt = sh.spillCnt[pass];            // written in pass 0, read-only since its closing barrier
@@ -1468,6 +1482,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
       emit_claimed<BH_SLOTS / BIG_NW / WAVE>(sh.tab, w * per, per, &sh.emitted, outBase, outEnd, JC, C);
       __syncthreads();
       STAMP(4);
+      ++pass;
     }
     if (tid == 0 && sh.emitted != want) atomicOr(err, ERRF_COUNT_MISMATCH);
     __syncthreads();

@@ -161,6 +161,7 @@ struct spgemm_handle {
   int2* spill = nullptr;
   int spill_blocks = 0;
   int bhCap = BH_CAP;
+  int bhMargin = 125;                // parking region per hash class, % of products/npass (SPGEMM_BHMARGIN; tests force overflows)
   int h1sym = 32;                    // blocks per CU of the wave-per-row symbolic kernel (SPGEMM_H1SYM, experiments)
   spgemm_stats stats;
 };
@@ -218,6 +219,7 @@ extern "C" int spgemm_hip_create(spgemm_handle** out, int device) {
   for (auto& u : h->kused) u = false;
   { const char* e = getenv("SPGEMM_CONCURRENT"); h->serial = !(e && e[0] == '1'); }
   { const char* e = getenv("SPGEMM_H1SYM"); if (e) { const int c = atoi(e); if (c >= 1 && c <= 32) h->h1sym = c; } }
+  { const char* e = getenv("SPGEMM_BHMARGIN"); if (e) { const int c = atoi(e); if (c >= 10 && c <= 400) h->bhMargin = c; } }
   { const char* e = getenv("SPGEMM_BHCAP"); if (e) { const int c = atoi(e); if (c >= 1024 && c <= BH_CAP_MAX) h->bhCap = c; } }
   { const char* e = getenv("SPGEMM_U"); if (e) { const int u = atoi(e); if (u == 2 || u == 4 || u == 8) h->U = u; } }
   for (auto& st : h->side) {
@@ -443,7 +445,7 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const int* dJA, cons
       }
       hipLaunchKernelGGL(k_num_bighash, dim3(blocks), dim3(BIG_THREADS), sizeof(BigHashShared), st,
                          bp, 8, rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 4, h->rowFlops,
-                         h->spill_blocks >= blocks ? h->spill : (int2*)nullptr, BH_SPILL, h->bhCap); }
+                         h->spill_blocks >= blocks ? h->spill : (int2*)nullptr, BH_SPILL, h->bhCap, h->bhMargin); }
   }
   if (rows(7, 8) > 0) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_NUM_HASH8, st);
     LAUNCH_U(k_num_hash, 8, 8192, dim3(clampi(rows(7, 8), 1, cu * 2)), dim3(512), st, bp, 7,

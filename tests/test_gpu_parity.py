@@ -237,6 +237,30 @@ def test_big_rows_wider_than_one_symbolic_window():
     assert_parity(hip_mul(A, B), want, what="wide-B big rows")
 
 
+def test_parking_region_overflow_redoes_the_row():
+    """Multi-pass rows park the products of later hash classes in per-class regions sized from the expected class
+    size; SPGEMM_BHMARGIN=60 makes every region too small, so each such row must notice the overflow and redo itself
+    with one walk per pass.  Same result either way."""
+    rng = np.random.default_rng(29)
+    k, n = 3000, 600000
+    B = _rows_csr([np.sort(rng.choice(n, size=int(rng.integers(40, 100)), replace=False)) for _ in range(k)], n, 7)
+    A = _rows_csr([rng.choice(k, size=s, replace=False) for s in (500, 260, 90, 1200)], k, 8)
+    want = po.sequential_spmm(A, B)
+    assert np.diff(want.rowPtr).max() > 3 * 10240
+    os.environ["SPGEMM_BHMARGIN"] = "60"
+    try:
+        h = hs.Handle(0)                                   # the knob is read when a handle is created
+    finally:
+        del os.environ["SPGEMM_BHMARGIN"]
+    dA, dB = to_hs(A).toGpuCSR(), to_hs(B).toGpuCSR()
+    dC = hs.gpuSpMMWrapper(dA, dB, h)
+    got = dC.toCpuCSR()
+    for d in (dC, dA, dB):
+        d.deviceDispose()
+    h.close()
+    assert_parity(got, want, what="parking overflow -> redo")
+
+
 def test_long_A_rows_and_empty_B_rows_in_staging():
     """A rows longer than one staging chunk (1024 / 512 / 64 entries) whose B rows are short or empty."""
     rng = np.random.default_rng(11)
