@@ -109,13 +109,15 @@ def main():
     out = None
     gather = not args.no_gather
     for _ in range(args.warmup):
-        out = job.step(gather)
+        out = None                                     # the consumer is done with the previous C: its arrays go back
+        out = job.step(gather)                         # to the caching allocator and the next step reuses them
     kern_ms = {}
     phase_ms = {"ms_classify": 0.0, "ms_symbolic": 0.0, "ms_scan_alloc": 0.0, "ms_numeric": 0.0, "ms_total": 0.0}
     barrier()
     t0 = time.perf_counter()
     dev_ms = 0.0
     for _ in range(args.steps):
+        out = None
         out = job.step(gather)
         st = engine.stats()
         dev_ms += st["ms_total"]                       # HIP-event durations of this step's launches (handle's stream)

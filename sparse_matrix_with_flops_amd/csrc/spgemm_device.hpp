@@ -1211,7 +1211,8 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sym_big(const int* __restrict__
     for (int w0 = 0; w0 < n; w0 += SYM_WC) {
       const int wc = min(SYM_WC, n - w0);
       const int words = (wc + 31) >> 5;
-      for (int i = tid; i < words; i += BIG_THREADS) sh.bitmap[i] = 0u;
+      const int words4 = (words + 3) & ~3;             // the bitmap is cleared and counted four words at a time
+      for (int i = tid * 4; i < words4; i += BIG_THREADS * 4) *reinterpret_cast<uint4*>(&sh.bitmap[i]) = make_uint4(0u, 0u, 0u, 0u);
       __syncthreads();
       for_each_product<BIG_NW, BIG_U, false>(sh.st, as, ae, JA, nullptr, IB, JB, nullptr,
                                              [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&)[BIG_U]) {
@@ -1219,11 +1220,14 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sym_big(const int* __restrict__
         for (int u = 0; u < BIG_U; ++u) {            // predicated by value: OR-ing 0 changes nothing
           const int c = col[u] - w0;
           const bool ok = act[u] && (unsigned)c < (unsigned)wc;
-          atomicOr(&sh.bitmap[ok ? c >> 5 : 0], ok ? 1u << (c & 31) : 0u);
+          atomicOr(ok ? &sh.bitmap[c >> 5] : reinterpret_cast<unsigned*>(&sh.st.dummy[threadIdx.x]), ok ? 1u << (c & 31) : 0u);
         }
       });
       int mine = 0;
-      for (int i = tid; i < words; i += BIG_THREADS) mine += __popc(sh.bitmap[i]);
+      for (int i = tid * 4; i < words4; i += BIG_THREADS * 4) {
+        const uint4 v4 = *reinterpret_cast<const uint4*>(&sh.bitmap[i]);
+        mine += __popc(v4.x) + __popc(v4.y) + __popc(v4.z) + __popc(v4.w);
+      }
       if (n <= BIG_WC && q < saveCap) {
         unsigned* dst = saveBitmaps + (size_t)q * BIG_WORDS;
         for (int i = tid; i < BIG_WORDS; i += BIG_THREADS) dst[i] = i < words ? sh.bitmap[i] : 0u;
