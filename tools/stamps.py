@@ -5,8 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparse_matrix_with_flops_amd import hipspgemm as hs, synth
 hs.LIB_PATH = os.path.join(os.path.dirname(hs.LIB_PATH), "libspgemm_hip_stamps.so")
 wl = sys.argv[1] if len(sys.argv) > 1 else "256k"
-m, seed = (262144, 42) if wl == "256k" else (1 << 20, 43)
-rp, ci, v = synth.powerlaw_csr(m, seed, 2)
+m, seed, base = {"256k": (262144, 42, 2), "1m": (1 << 20, 43, 2), "1m32": (1 << 20, 44, 4)}[wl]
+rp, ci, v = synth.powerlaw_csr(m, seed, base)
 h = hs.Handle(0)
 A = hs.CSR.from_arrays(rp, ci, v, m, m).toGpuCSR()
 for it in range(3):
