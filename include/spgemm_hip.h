@@ -171,6 +171,21 @@ int hip_gpuRmclIter(int maxIter, int rows, int cols,
                     const int* tIA, const int* tJA, const float* tA, int tnnz,
                     int** oIA, int** oJA, float** oA, int* onnz);
 
+/* ---- the step in front of the path: COO -> CSR on device arrays -------------
+ * Replaces COO::addSelfLoopIfNeeded (nlibs/COO.cc:160-188), COO::makeOrdered / orderedAndDuplicatesRemoving
+ * (nlibs/COO.cc:222-266: std::sort on (row,col), duplicates summed), COO::toCSR (nlibs/COO.cc:268-291),
+ * CSR::averAndNormRowQValue (nlibs/CSR.cc:88-95) and CSR::toAbs (nlibs/CSR.h:152-158): what rmclInit
+ * (nlibs/qrmcl.cc:126-134 = SELF_LOOPS | ROW_NORMALISE) and the Matrix-Market / SNAP loaders (= DEDUPE) do after
+ * parsing.  dRow/dCol/dVal: device COO (any order).  Outputs: device CSR from the library pool (release with
+ * spgemm_hip_free); rows column-sorted.  Duplicates are summed in input order (bit-exact with the CPU loop).
+ * Entries outside rows x cols -> SPGEMM_ERR_INPUT. */
+#define SPGEMM_COO_DEDUPE         1   /* sum duplicates of one (row,col)                              */
+#define SPGEMM_COO_SELF_LOOPS     2   /* append (i,i,1.0) for every row without a diagonal entry      */
+#define SPGEMM_COO_ROW_NORMALISE  4   /* every entry of row i becomes 1/count(i)                      */
+#define SPGEMM_COO_ABS            8   /* |value|                                                      */
+int hip_coo_to_csr(spgemm_handle* h, int rows, int cols, int nnz, const int* dRow, const int* dCol, const float* dVal,
+                   int flags, int** dIA, int** dJA, float** dA, int* nnzOut);
+
 /* ---- helpers the reference's drivers use around the path --------------------------------------- */
 /* CSR::makeOrdered on device arrays (nlibs/CSR.cc:73-86): sort every row by column, in place. */
 int hip_csr_sort_rows(spgemm_handle* h, int m, const int* dIC, int* dJC, float* dC);

@@ -1,0 +1,194 @@
+// COO -> CSR on the device: the step in front of the SpGEMM path.
+//
+// Replaces, on device arrays,
+//   COO::addSelfLoopIfNeeded                       nlibs/COO.cc:160-188
+//   COO::makeOrdered / orderedAndDuplicatesRemoving nlibs/COO.cc:222-266   (std::sort on (row,col) tuples; duplicates summed)
+//   COO::toCSR                                      nlibs/COO.cc:268-291
+//   CSR::averAndNormRowQValue                       nlibs/CSR.cc:88-95      (every entry of row i becomes 1/count(i))
+//   CSR::toAbs                                      nlibs/CSR.h:152-158
+// i.e. what rmclInit (nlibs/qrmcl.cc:126-134) and the Matrix-Market/SNAP loaders do after parsing the text.
+//
+// The sort is a stable LSD radix sort (rocPRIM through hipCUB: a library sort is fine here, this is not the hot path)
+// of the 64-bit key row*cols+col carrying the entry's input position, over exactly the bits the shape needs.  Stable
+// order = input order inside a run of equal (row,col), so duplicates are summed left to right like the CPU loop
+// (bit-exact floats).  Included at the end of spgemm_hip.hip (uses its pool / error helpers).
+#pragma once
+#include <hipcub/hipcub.hpp>
+
+namespace coo {
+
+__global__ void k_check_and_diag(int nnz, int rows, int cols, const int* __restrict__ ri, const int* __restrict__ ci,
+                                 unsigned char* __restrict__ hasDiag, int* __restrict__ bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nnz) return;
+  const int r = ri[i], c = ci[i];
+  if ((unsigned)r >= (unsigned)rows || (unsigned)c >= (unsigned)cols) { atomicOr(bad, 1); return; }
+  if (hasDiag && r == c) hasDiag[r] = 1;
+}
+
+__global__ void k_missing_flags(int rows, const unsigned char* __restrict__ hasDiag, int* __restrict__ miss) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) miss[r] = hasDiag[r] ? 0 : 1;
+}
+
+// keys of the original entries and of the appended self loops; payload = position in the (extended) input
+__global__ void k_make_keys(int nnz, int rows, int cols, const int* __restrict__ ri, const int* __restrict__ ci,
+                            const int* __restrict__ missPos, const int* __restrict__ miss,
+                            unsigned long long* __restrict__ keys, int* __restrict__ idx, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nnz) {
+    keys[i] = (unsigned long long)(unsigned)ri[i] * (unsigned long long)(unsigned)cols + (unsigned)ci[i];
+    idx[i] = i;
+  }
+  if (miss && i < rows && miss[i]) {            // self loop (i,i,1.0) appended behind the input, in row order
+    const int p = nnz + missPos[i];
+    keys[p] = (unsigned long long)(unsigned)i * (unsigned long long)(unsigned)cols + (unsigned)i;
+    idx[p] = p;
+  }
+  (void)total;
+}
+
+__global__ void k_heads(int n, const unsigned long long* __restrict__ keys, int dedupe, int* __restrict__ head) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) head[i] = (!dedupe || i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+// one thread per output entry (= head of a run of equal keys): column, summed value, row count
+__global__ void k_emit(int n, int nnzIn, int cols, const unsigned long long* __restrict__ keys, const int* __restrict__ idx,
+                       const int* __restrict__ head, const int* __restrict__ pos, const float* __restrict__ val,
+                       int dedupe, int useAbs, int* __restrict__ JA, float* __restrict__ A, int* __restrict__ rowCnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !head[i]) return;
+  const unsigned long long k = keys[i];
+  const int src = idx[i];
+  float s = src < nnzIn ? val[src] : 1.0f;       // appended self loops carry 1.0
+  if (dedupe)
+    for (int j = i + 1; j < n && keys[j] == k; ++j) { const int sj = idx[j]; s += sj < nnzIn ? val[sj] : 1.0f; }
+  const int r = (int)(k / (unsigned long long)(unsigned)cols), c = (int)(k - (unsigned long long)r * (unsigned)cols);
+  const int o = pos[i];
+  JA[o] = c;
+  A[o] = useAbs ? fabsf(s) : s;
+  atomicAdd(&rowCnt[r + 1], 1);                  // integer counts: the result does not depend on the order
+}
+
+__global__ void k_row_normalise(int rows, const int* __restrict__ IA, float* __restrict__ A) {
+  const int r = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4), gl = threadIdx.x & 15;
+  if (r >= rows) return;
+  const int s = IA[r], e = IA[r + 1];
+  const float w = (float)(1.0 / (double)(e - s));  // double division, narrowed (nlibs/CSR.cc:88-95)
+  for (int p = s + gl; p < e; p += 16) A[p] = w;
+}
+
+}  // namespace coo
+
+extern "C" int hip_coo_to_csr(spgemm_handle* h, int rows, int cols, int nnz, const int* dRow, const int* dCol,
+                              const float* dVal, int flags, int** dIA, int** dJA, float** dA, int* nnzOut) {
+  if (!dIA || !dJA || !dA || !nnzOut) return fail(SPGEMM_ERR_ARG, "output pointer is null");
+  *dIA = nullptr; *dJA = nullptr; *dA = nullptr; *nnzOut = 0;
+  if (rows < 0 || cols < 0 || nnz < 0) return fail(SPGEMM_ERR_ARG, "negative size");
+  if (nnz > 0 && (!dRow || !dCol || !dVal)) return fail(SPGEMM_ERR_ARG, "COO arrays null with nnz=%d", nnz);
+  if ((flags & SPGEMM_COO_SELF_LOOPS) && rows != cols) return fail(SPGEMM_ERR_ARG, "self loops need a square matrix");
+  if (!h) CHK(default_handle(&h));
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const int dedupe = (flags & SPGEMM_COO_DEDUPE) ? 1 : 0;
+  const bool loops = (flags & SPGEMM_COO_SELF_LOOPS) != 0;
+  const long long maxTotal = (long long)nnz + (loops ? rows : 0);
+  if (maxTotal > 0x7fffffffLL) return fail(SPGEMM_ERR_OVERFLOW, "nnz does not fit int32");
+
+  unsigned char* hasDiag = nullptr;
+  int *bad = nullptr, *miss = nullptr, *missPos = nullptr, *idxA = nullptr, *idxB = nullptr, *head = nullptr, *pos = nullptr;
+  unsigned long long *keyA = nullptr, *keyB = nullptr;
+  void* tmp = nullptr;
+  int *IA = nullptr, *JA = nullptr;
+  float* A = nullptr;
+  auto cleanup = [&](int rc) {
+    for (void* p : {(void*)hasDiag, (void*)bad, (void*)miss, (void*)missPos, (void*)idxA, (void*)idxB, (void*)head,
+                    (void*)pos, (void*)keyA, (void*)keyB, tmp})
+      pool().release(p);
+    if (rc != SPGEMM_OK) { pool().release(IA); pool().release(JA); pool().release(A); }
+    return rc;
+  };
+#define COO_ALLOC(ptr, bytes) if (pool().alloc((void**)&(ptr), (bytes)) != hipSuccess) return cleanup(fail(SPGEMM_ERR_HIP, "device allocation failed"))
+#define COO_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return cleanup(fail(SPGEMM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
+  const int T = 256;
+  auto grid = [&](long long n) { return dim3((unsigned)std::max<long long>(1, (n + T - 1) / T)); };
+  size_t tmpBytes = 0, need = 0;
+  hipcub::DeviceScan::ExclusiveSum(nullptr, need, (int*)nullptr, (int*)nullptr, (int)std::max<long long>(maxTotal, (long long)rows + 1));
+  tmpBytes = need;
+  const int keyBits = std::max(1, 64 - __builtin_clzll((unsigned long long)std::max(1, rows) * (unsigned long long)std::max(1, cols)));
+  hipcub::DeviceRadixSort::SortPairs(nullptr, need, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr,
+                                     (int*)nullptr, (int)std::max<long long>(maxTotal, 1), 0, keyBits);
+  tmpBytes = std::max(tmpBytes, need);
+  COO_ALLOC(tmp, tmpBytes);
+  COO_ALLOC(bad, sizeof(int));
+  COO_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
+  // (1) validation, diagonal flags, self loops to append
+  int extra = 0;
+  if (loops && rows > 0) {
+    COO_ALLOC(hasDiag, (size_t)rows);
+    COO_ALLOC(miss, sizeof(int) * (size_t)rows);
+    COO_ALLOC(missPos, sizeof(int) * (size_t)rows);
+    COO_HIP(hipMemsetAsync(hasDiag, 0, (size_t)rows, s));
+  }
+  if (nnz > 0) hipLaunchKernelGGL(coo::k_check_and_diag, grid(nnz), dim3(T), 0, s, nnz, rows, cols, dRow, dCol, hasDiag, bad);
+  if (loops && rows > 0) {
+    hipLaunchKernelGGL(coo::k_missing_flags, grid(rows), dim3(T), 0, s, rows, hasDiag, miss);
+    need = tmpBytes;
+    COO_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, need, miss, missPos, rows, s));
+    int lastFlag = 0, lastPos = 0;
+    COO_HIP(hipMemcpyAsync(&lastFlag, miss + rows - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    COO_HIP(hipMemcpyAsync(&lastPos, missPos + rows - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    COO_HIP(hipStreamSynchronize(s));
+    extra = lastPos + lastFlag;
+  }
+  int hbad = 0;
+  COO_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
+  COO_HIP(hipStreamSynchronize(s));
+  if (hbad) return cleanup(fail(SPGEMM_ERR_INPUT, "COO entry outside the %d x %d matrix", rows, cols));
+  const int total = nnz + extra;
+  COO_ALLOC(IA, sizeof(int) * ((size_t)rows + 1));
+  COO_HIP(hipMemsetAsync(IA, 0, sizeof(int) * ((size_t)rows + 1), s));
+  if (total == 0) {
+    COO_ALLOC(JA, sizeof(int));
+    COO_ALLOC(A, sizeof(float));
+    COO_HIP(hipStreamSynchronize(s));
+    *dIA = IA; *dJA = JA; *dA = A; *nnzOut = 0;
+    return cleanup(SPGEMM_OK);
+  }
+  // (2) keys + stable sort
+  COO_ALLOC(keyA, sizeof(unsigned long long) * (size_t)total);
+  COO_ALLOC(keyB, sizeof(unsigned long long) * (size_t)total);
+  COO_ALLOC(idxA, sizeof(int) * (size_t)total);
+  COO_ALLOC(idxB, sizeof(int) * (size_t)total);
+  hipLaunchKernelGGL(coo::k_make_keys, grid(std::max(nnz, loops ? rows : 0)), dim3(T), 0, s, nnz, rows, cols, dRow, dCol,
+                     missPos, loops ? miss : (int*)nullptr, keyA, idxA, total);
+  need = tmpBytes;
+  COO_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, need, keyA, keyB, idxA, idxB, total, 0, keyBits, s));
+  // (3) heads of runs -> output positions
+  COO_ALLOC(head, sizeof(int) * (size_t)total);
+  COO_ALLOC(pos, sizeof(int) * (size_t)total);
+  hipLaunchKernelGGL(coo::k_heads, grid(total), dim3(T), 0, s, total, keyB, dedupe, head);
+  need = tmpBytes;
+  COO_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, need, head, pos, total, s));
+  int lastHead = 0, lastPos = 0;
+  COO_HIP(hipMemcpyAsync(&lastHead, head + total - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+  COO_HIP(hipMemcpyAsync(&lastPos, pos + total - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+  COO_HIP(hipStreamSynchronize(s));
+  const int outN = lastPos + lastHead;
+  // (4) emit columns / values / row counts, scan the counts, optional row normalisation
+  COO_ALLOC(JA, sizeof(int) * (size_t)std::max(outN, 1));
+  COO_ALLOC(A, sizeof(float) * (size_t)std::max(outN, 1));
+  hipLaunchKernelGGL(coo::k_emit, grid(total), dim3(T), 0, s, total, nnz, cols, keyB, idxB, head, pos, dVal, dedupe,
+                     (flags & SPGEMM_COO_ABS) ? 1 : 0, JA, A, IA);
+  need = tmpBytes;
+  COO_HIP(hipcub::DeviceScan::InclusiveSum(tmp, need, IA, IA, rows + 1, s));
+  if ((flags & SPGEMM_COO_ROW_NORMALISE) && rows > 0)
+    hipLaunchKernelGGL(coo::k_row_normalise, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, rows, IA, A);
+  COO_HIP(hipGetLastError());
+  COO_HIP(hipStreamSynchronize(s));
+#undef COO_ALLOC
+#undef COO_HIP
+  *dIA = IA; *dJA = JA; *dA = A; *nnzOut = outN;
+  return cleanup(SPGEMM_OK);
+}

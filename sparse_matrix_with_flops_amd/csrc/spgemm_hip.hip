@@ -958,3 +958,8 @@ extern "C" int spgemm_hip_debug_stamps(unsigned long long* out /*[4][16]*/, int 
   return SPGEMM_OK;
 }
 #endif
+
+// ------------------------------------------------------------------------------------------------
+// COO -> CSR on the device (the step in front of the path)
+// ------------------------------------------------------------------------------------------------
+#include "coo_device.hpp"

@@ -33,7 +33,7 @@ EXPORTS = [
     "spgemm_hip_memcpy_h2d", "spgemm_hip_memcpy_d2h", "spgemm_hip_memcpy_d2d", "hip_CSR_SpMM", "hip_gpuSpMM",
     "hip_gpuFlopsClassify", "hip_sgpuSpMM", "hip_csr_sort_rows", "spgemm_hip_selftest",
     "hip_spgemm_symbolic", "hip_spgemm_numeric", "hip_csr_row_flops", "spgemm_hip_kernel_name",
-    "hip_rmcl_prune", "hip_gpuRmclIter",
+    "hip_rmcl_prune", "hip_gpuRmclIter", "hip_coo_to_csr",
 ]
 
 
@@ -94,6 +94,8 @@ def lib():
                                         C.POINTER(C.c_longlong)]
         L.spgemm_hip_kernel_name.restype = C.c_char_p
         L.spgemm_hip_kernel_name.argtypes = [C.c_int]
+        L.hip_coo_to_csr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I]
         L.spgemm_hip_memcpy_d2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.hip_rmcl_prune.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + \
             [C.POINTER(C.c_void_p)] * 3 + [_I]
@@ -301,6 +303,33 @@ def rmcl_prune_raw(handle, m, IC, JC, CV):
     _check(lib().hip_rmcl_prune(handle.ptr if handle else None, int(m), C.c_void_p(IC), C.c_void_p(JC), C.c_void_p(CV),
                                 C.byref(i_), C.byref(j_), C.byref(c_), C.byref(n_)), "hip_rmcl_prune")
     return i_.value, j_.value, c_.value, n_.value
+
+
+COO_DEDUPE, COO_SELF_LOOPS, COO_ROW_NORMALISE, COO_ABS = 1, 2, 4, 8
+
+
+def coo_to_csr_raw(handle, rows, cols, nnz, dRow, dCol, dVal, flags):
+    """hip_coo_to_csr on raw device pointers -> (dIA, dJA, dA, nnz) from the library pool (release with dev_free)."""
+    ia, ja, av, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+    _check(lib().hip_coo_to_csr(handle.ptr if handle else None, int(rows), int(cols), int(nnz), C.c_void_p(dRow),
+                                C.c_void_p(dCol), C.c_void_p(dVal), int(flags), C.byref(ia), C.byref(ja), C.byref(av),
+                                C.byref(n)), "hip_coo_to_csr")
+    return ia.value, ja.value, av.value, n.value
+
+
+def coo_to_csr(rows, cols, ri, ci, v, flags, handle=None):
+    """Host COO arrays in, device CSR out (COO::toCSR and friends, on the device): returns a device `CSR`.
+    flags: COO_DEDUPE | COO_SELF_LOOPS | COO_ROW_NORMALISE | COO_ABS (rmclInit = SELF_LOOPS | ROW_NORMALISE)."""
+    ri = np.ascontiguousarray(ri, dtype=np.int32)
+    ci = np.ascontiguousarray(ci, dtype=np.int32)
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    dr, dc, dv = h2d(ri), h2d(ci), h2d(v)
+    try:
+        ia, ja, av, n = coo_to_csr_raw(handle, rows, cols, len(ri), dr, dc, dv, flags)
+    finally:
+        for p in (dr, dc, dv):
+            dev_free(p)
+    return CSR(av, ja, ia, rows, cols, n, True)
 
 
 def row_flops_raw(handle, IA, JA, IB, m, out_ptr):

@@ -1,0 +1,87 @@
+"""GPU (-m gpu): COO -> CSR on the device (hip_coo_to_csr: sort, duplicate summing, self loops, row normalisation, abs)
+against the CPU oracle's restatement of COO::makeOrdered / orderedAndDuplicatesRemoving / toCSR / addSelfLoopIfNeeded /
+averAndNormRowQValue and of rmclInit -- bit for bit, floats included (duplicates are summed in input order on both
+sides) -- and against the CSRs the real reference loads from its own fixture files (tests/golden/fixtures.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import DATA, GOLDEN, po, synth_csr
+from sparse_matrix_with_flops_amd import hipspgemm as hs
+
+pytestmark = pytest.mark.gpu
+FX = np.load(os.path.join(GOLDEN, "fixtures.npz"))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import __graft_entry__ as ge
+    ge.build()
+    assert hs.device_count() >= 1
+
+
+def bits_equal(dev, want):
+    got = dev.toCpuCSR()
+    dev.deviceDispose()
+    assert got.rows == want.rows and got.nnz == want.nnz
+    assert np.array_equal(got.rowPtr, want.rowPtr) and np.array_equal(got.colInd, want.colInd)
+    assert np.array_equal(got.values.view(np.uint32), np.asarray(want.values, np.float32).view(np.uint32))
+
+
+def random_coo(rows, cols, nnz, seed, dup_frac=0.2, signed=True):
+    rng = np.random.default_rng(seed)
+    ri = rng.integers(0, rows, size=nnz).astype(np.int32)
+    ci = rng.integers(0, cols, size=nnz).astype(np.int32)
+    ndup = int(nnz * dup_frac)
+    src = rng.integers(0, nnz, size=ndup)                       # repeat some (row,col) pairs, several times for a few
+    dst = rng.integers(0, nnz, size=ndup)
+    ri[dst], ci[dst] = ri[src], ci[src]
+    v = (rng.random(nnz) + 0.25).astype(np.float32)
+    if signed:
+        v *= rng.choice(np.array([-1.0, 1.0], np.float32), size=nnz)
+    return ri, ci, v
+
+
+@pytest.mark.parametrize("rows,cols,nnz,seed", [(1, 1, 1, 1), (7, 5, 40, 2), (300, 300, 5000, 3), (5000, 70000, 200000, 4),
+                                                (200000, 200000, 3000000, 5)])
+@pytest.mark.parametrize("dedupe", [True, False])
+def test_sort_dedupe_to_csr_matches_oracle(rows, cols, nnz, seed, dedupe):
+    ri, ci, v = random_coo(rows, cols, nnz, seed)
+    want = po.coo_to_csr(rows, cols, ri, ci, v, dedupe=dedupe)
+    bits_equal(hs.coo_to_csr(rows, cols, ri, ci, v, hs.COO_DEDUPE if dedupe else 0), want)
+
+
+def test_abs_flag_and_empty_input():
+    ri, ci, v = random_coo(50, 60, 400, 9)
+    bits_equal(hs.coo_to_csr(50, 60, ri, ci, v, hs.COO_DEDUPE | hs.COO_ABS), po.coo_to_csr(50, 60, ri, ci, v, dedupe=True, toAbs=True))
+    z = np.zeros(0, np.int32)
+    E = hs.coo_to_csr(4, 4, z, z, np.zeros(0, np.float32), hs.COO_DEDUPE)
+    e = E.toCpuCSR()
+    E.deviceDispose()
+    assert e.nnz == 0 and np.array_equal(e.rowPtr, np.zeros(5, np.int32))
+
+
+@pytest.mark.parametrize("m,seed", [(2000, 11), (60000, 12)])
+def test_rmcl_init_on_device_matches_oracle(m, seed):
+    """rmclInit = self loops for rows without a diagonal entry + sort (no dedupe) + toCSR + 1/count values."""
+    A = synth_csr(m, seed, 2)
+    ri = np.repeat(np.arange(A.rows, dtype=np.int32), np.diff(A.rowPtr))
+    perm = np.random.default_rng(seed).permutation(A.nnz)                  # the loader sees edges in file order
+    ri, ci, v = ri[perm], A.colInd[perm], np.ones(A.nnz, np.float32)
+    want = po.rmcl_init(A.rows, A.cols, ri, ci, v)
+    bits_equal(hs.coo_to_csr(A.rows, A.cols, ri, ci, v, hs.COO_SELF_LOOPS | hs.COO_ROW_NORMALISE), want)
+
+
+@pytest.mark.parametrize("name", ["test.mtx", "test2.mtx", "own_dups.mtx", "own_sym.mtx", "own_pattern.mtx", "own_graph.snap", "t2.snap"])
+def test_reference_fixture_files(name):
+    """COO as the loader parses it (oracle text reader) -> device COO->CSR == the CSR the real reference loaded."""
+    rows, cols, ri, ci, v = po.read_snap(os.path.join(DATA, name), False)
+    key = name.replace(".", "_") + "_load"
+    want = po.CSRHost(FX[key + "_rowPtr"], FX[key + "_colInd"], FX[key + "_values"], *[int(x) for x in FX[key + "_shape"]])
+    bits_equal(hs.coo_to_csr(rows, cols, ri, ci, v, hs.COO_DEDUPE), want)
+
+
+def test_out_of_range_entry_is_an_error():
+    with pytest.raises(hs.SpgemmError):
+        hs.coo_to_csr(3, 3, np.array([0, 5], np.int32), np.array([1, 1], np.int32), np.ones(2, np.float32), hs.COO_DEDUPE)
