@@ -1,6 +1,7 @@
 // COO.cc — see COO.h.  Own implementation of the loader / sort / dedupe / toCSR steps with the reference's
 // semantics (nlibs/COO.cc:48-291); plain host code, no device work.
 #include "COO.h"
+#include "../../../include/spgemm_hip.h"
 
 #include <algorithm>
 #include <cctype>
@@ -132,4 +133,19 @@ CSR COO::toCSR() const {
   memcpy(ci, cooColIndex, sizeof(int) * (size_t)nnz);
   memcpy(v, cooVal, sizeof(QValue) * (size_t)nnz);
   return CSR(v, ci, rp, rows, cols, nnz);
+}
+
+// COO -> device CSR without the host std::sort: hip_coo_to_csr does sort / duplicate summing / self loops / row
+// normalisation / abs on the device (include/spgemm_hip.h).  Exit-on-error like the rest of the mirror.
+CSR COO::toGpuCSR(int flags) const {
+  int *dR = 0, *dC = 0; QValue* dV = 0;
+  CSR d; d.rows = rows; d.cols = cols;
+  const size_t nI = sizeof(int) * (size_t)nnz, nV = sizeof(QValue) * (size_t)nnz;
+  int rc = spgemm_hip_malloc((void**)&dR, nI) || spgemm_hip_malloc((void**)&dC, nI) || spgemm_hip_malloc((void**)&dV, nV) ||
+           spgemm_hip_memcpy_h2d(dR, cooRowIndex, nI) || spgemm_hip_memcpy_h2d(dC, cooColIndex, nI) ||
+           spgemm_hip_memcpy_h2d(dV, cooVal, nV) ||
+           hip_coo_to_csr(NULL, rows, cols, nnz, dR, dC, dV, flags, &d.rowPtr, &d.colInd, &d.values, &d.nnz);
+  spgemm_hip_free(dR); spgemm_hip_free(dC); spgemm_hip_free(dV);
+  if (rc) { printf("%s\n", spgemm_hip_last_error()); exit(EXIT_FAILURE); }
+  return d;
 }

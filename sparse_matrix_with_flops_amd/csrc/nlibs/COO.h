@@ -20,5 +20,8 @@ class COO {
   void makeOrdered() const;             // nlibs/COO.cc:222-235: sort by (row, col)
   int orderedAndDuplicatesRemoving();   // nlibs/COO.cc:237-266: sort + sum duplicates
   CSR toCSR() const;                    // nlibs/COO.cc:268-291 (input must be ordered)
+  // the same three steps on the device in one call (hip_coo_to_csr): upload the triplets in file order, get a
+  // DEVICE CSR back.  flags: SPGEMM_COO_DEDUPE | SPGEMM_COO_SELF_LOOPS | SPGEMM_COO_ROW_NORMALISE | SPGEMM_COO_ABS
+  CSR toGpuCSR(int flags) const;
 };
 #endif

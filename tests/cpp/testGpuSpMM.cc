@@ -12,6 +12,7 @@
 #include "CSR.h"
 #include "gpus/gpu_csr_kernel.h"
 #include "qrmcl.h"
+#include "../../include/spgemm_hip.h"
 
 extern "C" {
 int oracle_sequential_spmm(const int*, const int*, const float*, int, const int*, const int*, const float*, int,
@@ -43,6 +44,18 @@ int main(int argc, char* argv[]) {
   coo.orderedAndDuplicatesRemoving();
   CSR A = coo.toCSR();
   A.toAbs();
+  {                                               // the loader's sort + dedupe + toCSR + toAbs on the device instead
+    COO raw;
+    raw.readSNAPFile(argv[1], false);
+    CSR dL = raw.toGpuCSR(SPGEMM_COO_DEDUPE | SPGEMM_COO_ABS);
+    CSR hL = dL.toCpuCSR();
+    dL.deviceDispose();
+    const bool bitEq = hL.rows == A.rows && hL.nnz == A.nnz && !memcmp(hL.rowPtr, A.rowPtr, sizeof(int) * ((size_t)A.rows + 1)) &&
+                     !memcmp(hL.colInd, A.colInd, sizeof(int) * (size_t)A.nnz) &&
+                     !memcmp(hL.values, A.values, sizeof(QValue) * (size_t)A.nnz);
+    bad += report("COO::toGpuCSR bit-equal", bitEq);
+    hL.dispose(); raw.dispose();
+  }
   coo.dispose();
   CSR B = A.deepCopy();
   CSR want = oracle_spmm(A, B);
