@@ -186,6 +186,13 @@ int hip_gpuRmclIter(int maxIter, int rows, int cols,
 int hip_coo_to_csr(spgemm_handle* h, int rows, int cols, int nnz, const int* dRow, const int* dCol, const float* dVal,
                    int flags, int** dIA, int** dJA, float** dA, int* nnzOut);
 
+/* ---- workload statistics ----------------------------------------------------
+ * std::vector<int> flopsStats(IA, JA, IB, JB, m) (nlibs/tools/stats.cc:29-55, pushToStats :3-12): 13 buckets of the
+ * per-row product count of A*B; bucket i counts rows with 2^(i-1) < flops <= 2^i, bucket 0 rows with flops <= 1,
+ * the last bucket rows above 2^11.  Device CSR arrays in, host histogram out. */
+#define SPGEMM_STATS_LEN 13
+int hip_flopsStats(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, int m, int stats[SPGEMM_STATS_LEN]);
+
 /* ---- helpers the reference's drivers use around the path --------------------------------------- */
 /* CSR::makeOrdered on device arrays (nlibs/CSR.cc:73-86): sort every row by column, in place. */
 int hip_csr_sort_rows(spgemm_handle* h, int m, const int* dIC, int* dJC, float* dC);

@@ -569,3 +569,16 @@ int oracle_rmcl_init(int rows, int nnz, int** rip, int** cip, QValue** vp,
   *rowPtrp = rp; *nnzOut = nnz;
   return 0;
 }
+
+/* pushToStats + flopsStats, nlibs/tools/stats.cc:3-12,45-55: 13 buckets, bucket i takes the first i with
+ * flops <= 2^i, the last bucket the rest. */
+void oracle_flops_stats(const int* IA, const int* JA, const int* IB, int m, int* stats /*[13]*/) {
+  for (int i = 0; i < 13; ++i) stats[i] = 0;
+  for (int i = 0; i < m; ++i) {
+    long row_flops = 0;
+    for (int jp = IA[i]; jp < IA[i + 1]; ++jp) row_flops += IB[JA[jp] + 1] - IB[JA[jp]];
+    int b = 12;
+    for (int q = 0; q < 12; ++q) if (row_flops <= (1l << q)) { b = q; break; }
+    ++stats[b];
+  }
+}

@@ -303,6 +303,13 @@ def rmcl_init(rows, cols, ri, ci, v):
     return A
 
 
+def flops_stats(A, B):
+    """flopsStats (nlibs/tools/stats.cc:45-55): 13-bucket power-of-two histogram of the per-row flops of A*B."""
+    out = np.zeros(13, dtype=np.int32)
+    lib().oracle_flops_stats(_ip(A.rowPtr), _ip(A.colInd), _ip(B.rowPtr), C.c_int(A.rows), _ip(out))
+    return out
+
+
 def rmcl_prune_row(cols, vals):
     cols, vals = _i32(cols).copy(), _f32(vals).copy()
     k = lib().oracle_rmcl_prune_row(C.c_int(len(cols)), _ip(cols), _fp(vals))

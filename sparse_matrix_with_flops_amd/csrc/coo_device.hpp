@@ -192,3 +192,48 @@ extern "C" int hip_coo_to_csr(spgemm_handle* h, int rows, int cols, int nnz, con
   *dIA = IA; *dJA = JA; *dA = A; *nnzOut = outN;
   return cleanup(SPGEMM_OK);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Workload statistics: the reference's 13-bucket power-of-two histogram of per-row flops
+// (pushToStats / flopsStats, nlibs/tools/stats.cc:3-55): bucket i counts rows with 2^(i-1) < flops <= 2^i, bucket 0
+// rows with flops <= 1, the last bucket everything above 2^11.  Row flops come from the path's own K1 kernel.
+// ------------------------------------------------------------------------------------------------
+namespace coo {
+__global__ void k_pow2_hist(int m, const int* __restrict__ val, int* __restrict__ hist /*[SPGEMM_STATS_LEN]*/) {
+  __shared__ int sh[SPGEMM_STATS_LEN];
+  if (threadIdx.x < SPGEMM_STATS_LEN) sh[threadIdx.x] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) {
+    const long long v = val[i];
+    int b = SPGEMM_STATS_LEN - 1;
+    for (int q = 0; q < SPGEMM_STATS_LEN - 1; ++q) if (v <= (1ll << q)) { b = q; break; }
+    atomicAdd(&sh[b], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < SPGEMM_STATS_LEN && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+}
+}  // namespace coo
+
+extern "C" int hip_flopsStats(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, int m,
+                              int stats[SPGEMM_STATS_LEN]) {
+  if (!stats) return fail(SPGEMM_ERR_ARG, "stats is null");
+  for (int i = 0; i < SPGEMM_STATS_LEN; ++i) stats[i] = 0;
+  if (m < 0 || !dIA) return fail(SPGEMM_ERR_ARG, "bad argument");
+  if (m == 0) return SPGEMM_OK;
+  if (!h) CHK(default_handle(&h));
+  HIPCHK(hipSetDevice(h->device));
+  int *flops = nullptr, *hist = nullptr;
+  auto cleanup = [&](int rc) { pool().release(flops); pool().release(hist); return rc; };
+  if (pool().alloc((void**)&flops, sizeof(int) * (size_t)m) != hipSuccess ||
+      pool().alloc((void**)&hist, sizeof(int) * SPGEMM_STATS_LEN) != hipSuccess)
+    return cleanup(fail(SPGEMM_ERR_HIP, "device allocation failed"));
+  int rc = hip_csr_row_flops(h, dIA, dJA, dIB, m, flops, nullptr);
+  if (rc) return cleanup(rc);
+  if (hipMemsetAsync(hist, 0, sizeof(int) * SPGEMM_STATS_LEN, h->stream) != hipSuccess) return cleanup(fail(SPGEMM_ERR_HIP, "memset failed"));
+  hipLaunchKernelGGL(coo::k_pow2_hist, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, m, flops, hist);
+  if (hipMemcpyAsync(stats, hist, sizeof(int) * SPGEMM_STATS_LEN, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+      hipStreamSynchronize(h->stream) != hipSuccess)
+    return cleanup(fail(SPGEMM_ERR_HIP, "flops statistics failed: %s", hipGetErrorString(hipGetLastError())));
+  return cleanup(SPGEMM_OK);
+}

@@ -33,7 +33,7 @@ EXPORTS = [
     "spgemm_hip_memcpy_h2d", "spgemm_hip_memcpy_d2h", "spgemm_hip_memcpy_d2d", "hip_CSR_SpMM", "hip_gpuSpMM",
     "hip_gpuFlopsClassify", "hip_sgpuSpMM", "hip_csr_sort_rows", "spgemm_hip_selftest",
     "hip_spgemm_symbolic", "hip_spgemm_numeric", "hip_csr_row_flops", "spgemm_hip_kernel_name",
-    "hip_rmcl_prune", "hip_gpuRmclIter", "hip_coo_to_csr",
+    "hip_rmcl_prune", "hip_gpuRmclIter", "hip_coo_to_csr", "hip_flopsStats",
 ]
 
 
@@ -96,6 +96,7 @@ def lib():
         L.spgemm_hip_kernel_name.argtypes = [C.c_int]
         L.hip_coo_to_csr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I]
+        L.hip_flopsStats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.spgemm_hip_memcpy_d2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.hip_rmcl_prune.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + \
             [C.POINTER(C.c_void_p)] * 3 + [_I]
@@ -306,6 +307,15 @@ def rmcl_prune_raw(handle, m, IC, JC, CV):
 
 
 COO_DEDUPE, COO_SELF_LOOPS, COO_ROW_NORMALISE, COO_ABS = 1, 2, 4, 8
+
+
+def flopsStats(dA, dB, handle=None):
+    """std::vector<int> flopsStats(...) (nlibs/tools/stats.cc:45-55) for device CSRs: 13 power-of-two buckets."""
+    assert dA.on_device and dB.on_device
+    out = (C.c_int * 13)()
+    _check(lib().hip_flopsStats(handle.ptr if handle else None, C.c_void_p(dA.rowPtr), C.c_void_p(dA.colInd),
+                                C.c_void_p(dB.rowPtr), dA.rows, out), "hip_flopsStats")
+    return [int(x) for x in out]
 
 
 def coo_to_csr_raw(handle, rows, cols, nnz, dRow, dCol, dVal, flags):

@@ -12,6 +12,7 @@
 #include "CSR.h"
 #include "gpus/gpu_csr_kernel.h"
 #include "qrmcl.h"
+#include "tools/stats.h"
 #include "../../include/spgemm_hip.h"
 
 extern "C" {
@@ -62,6 +63,7 @@ int main(int argc, char* argv[]) {
   want.makeOrdered();
 
   CSR dA = A.toGpuCSR(), dB = B.toGpuCSR();
+  outputStats(gpuFlopsStats(dA, dB));            // tools/stats.cc report: rows by power-of-two flop class
   CSR dC = gpuSpMMWrapper(dA, dB);
   dA.deviceDispose(); dB.deviceDispose();
   CSR hC = dC.toCpuCSR();

@@ -85,3 +85,13 @@ def test_reference_fixture_files(name):
 def test_out_of_range_entry_is_an_error():
     with pytest.raises(hs.SpgemmError):
         hs.coo_to_csr(3, 3, np.array([0, 5], np.int32), np.array([1, 1], np.int32), np.ones(2, np.float32), hs.COO_DEDUPE)
+
+
+@pytest.mark.parametrize("m,seed", [(3000, 21), (262144, 42)])
+def test_flops_stats_match_oracle(m, seed):
+    """hip_flopsStats == the oracle's restatement of flopsStats (nlibs/tools/stats.cc:45-55)."""
+    A = synth_csr(m, seed, 2)
+    dA = hs.CSR.from_arrays(A.rowPtr, A.colInd, A.values, A.rows, A.cols).toGpuCSR()
+    got = hs.flopsStats(dA, dA)
+    dA.deviceDispose()
+    assert got == [int(x) for x in po.flops_stats(A, A)] and sum(got) == m

@@ -153,3 +153,19 @@ def test_threshold_math():
     assert L.oracle_compute_threshold(0.25, 0.5) == np.float32(0.90 * np.float32(0.25) * (1 - 2 * np.float32(0.25)))
     assert L.oracle_compute_threshold(0.0, 0.0) == 0.0          # clamps to max
     assert abs(L.oracle_compute_threshold(1e-9, 1.0) - 1e-7) < 1e-12
+
+
+def test_flops_stats_buckets():
+    """pushToStats (nlibs/tools/stats.cc:3-12): first bucket i with flops <= 2^i, 13 buckets, the last takes the rest."""
+    A = synth_csr(20000, 5, 2)
+    f = po.row_flops(A, A)
+    want = np.zeros(13, dtype=np.int64)
+    for x in f:
+        b = 12
+        for q in range(12):
+            if x <= (1 << q):
+                b = q
+                break
+        want[b] += 1
+    got = po.flops_stats(A, A)
+    assert got.sum() == A.rows and np.array_equal(got, want)
