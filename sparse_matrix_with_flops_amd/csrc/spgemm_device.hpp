@@ -126,10 +126,6 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ int lds_load(const int* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 __device__ __forceinline__ int next_pow2_clamped(int x, int lo, int hi) {
   int p = lo;
   while (p < x && p < hi) p <<= 1;
@@ -964,22 +960,6 @@ __device__ __forceinline__ PreA load_pre(const RowMeta& mtd, const int* JA, cons
   const int ap = mtd.as + lane_id();
   if (ap < mtd.ae) { p.j = JA[ap]; if (needVal) p.a = VA[ap]; }
   return p;
-}
-
-// block-wide exclusive scan of one int per thread (NW waves); returns exclusive value, *total = sum
-template <int NW>
-__device__ __forceinline__ int block_excl_scan(int v, int* red, int* total) {
-  const int lane = lane_id(), w = threadIdx.x >> 6;
-  const int incl = wave_incl_add(v);
-  if (NW == 1) { *total = __builtin_amdgcn_readlane(incl, 63); return incl - v; }
-  __syncthreads();
-  if (lane == 63) red[w] = incl;
-  __syncthreads();
-  int woff = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < NW; ++i) { const int s = red[i]; tot += s; if (i < w) woff += s; }
-  *total = tot;
-  return woff + incl - v;
 }
 
 // ------------------------------------------------------------------------------------------------
