@@ -1,0 +1,91 @@
+"""GPU (-m gpu): the N>1 path with the REAL engine.  Two ranks share the one GPU of the test box and talk over gloo
+(RCCL refuses two ranks on one device): dist.ShardedSpGEMM / dist.ShardedRMCL run their whole control flow on device
+tensors with libspgemm_hip.so doing the local work on every rank -- everything of the multi-GPU step except the RCCL
+transport itself, which only an 8-GPU node can exercise."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import assert_parity, po, synth_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _graph(m, seed):
+    A = synth_csr(m, seed, 2)
+    ri = np.repeat(np.arange(A.rows, dtype=np.int32), np.diff(A.rowPtr))
+    return po.rmcl_init(A.rows, A.cols, A.colInd, ri, np.ones_like(A.values))
+
+
+def _worker(rank, world, port, kind, m, seed, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from sparse_matrix_with_flops_amd.dist import HipEngine, ShardedRMCL, ShardedSpGEMM
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = HipEngine(0)
+        if kind == "spgemm":
+            A = synth_csr(m, seed, 2)
+            job = ShardedSpGEMM(eng, (A.rowPtr, A.colInd, A.values, A.rows, A.cols), None)
+            rp, jc, cv = job.step()
+            torch.cuda.synchronize()
+            q.put((rank, rp.cpu().numpy(), jc.cpu().numpy(), cv.cpu().numpy(), job.ends.copy()))
+        else:
+            Mt = _graph(m, seed)
+            host = (Mt.rowPtr, Mt.colInd, Mt.values, Mt.rows, Mt.cols)
+            job = ShardedRMCL(eng, host, host)
+            job.iterate(3)
+            rp, ci, v = job.result_host()
+            q.put((rank, rp, ci, v, job.ends.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(kind, m, seed, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, m, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(outs, key=lambda o: o[0])
+
+
+def test_sharded_spgemm_two_ranks_hip_engine():
+    m, seed = 40000, 19
+    outs = _run("spgemm", m, seed)
+    A = synth_csr(m, seed, 2)
+    want = po.omp_spmm(A, A)
+    for rank, rp, jc, cv, ends in outs:
+        assert 0 < ends[1] < m
+        assert_parity(po.CSRHost(rp, jc, cv, m, m), want, what=f"rank {rank}")      # every rank holds the whole C
+
+
+def test_sharded_rmcl_two_ranks_hip_engine():
+    m, seed = 20000, 31
+    outs = _run("rmcl", m, seed)
+    Mt = _graph(m, seed)
+    want = po.rmcl_iters(Mt, Mt, 3)
+    r0 = outs[0]
+    for rank, rp, ci, v, ends in outs:                                                # all ranks agree bit for bit
+        assert np.array_equal(rp, r0[1]) and np.array_equal(ci, r0[2]) and np.array_equal(v.view(np.uint32), r0[3].view(np.uint32))
+    gl, wl = np.diff(r0[1]), np.diff(want.rowPtr)
+    assert np.mean(gl != wl) < 1e-3 and abs(len(r0[2]) - want.nnz) <= max(20, want.nnz // 2000)   # threshold ties only
+    rs = np.add.reduceat(r0[3], r0[1][:-1][gl > 0])
+    assert np.allclose(rs, 1.0, atol=1e-4)
