@@ -159,7 +159,7 @@ int hip_sgpuSpMM(spgemm_handle* h,
 
 /* ---- R-MCL (the caller of the path) --------------------------------------
  * hip_rmcl_prune: the post-step of one iteration on device arrays: inflate / threshold-prune / normalise every row of
- * C (dIC[m+1], dJC, dC; dC is squared in place) and compact into new arrays (*dIN, *dJN, *dCN allocated here, release
+ * C (dIC[m+1], dJC, dC; inputs are not modified) and compact into new arrays (*dIN, *dJN, *dCN allocated here, release
  * with spgemm_hip_free).  CPU: nlibs/qrmcl.cc:96-117 + nlibs/tools/util.cc:4-69; reference GPU: nlibs/gpus/dutil.cuh.
  * hip_gpuRmclIter: void gpuRmclIter(const int maxIter, const CSR Mgt, CSR& Mt) (nlibs/gpus/gpu_csr_kernel.cu:281-311):
  * host CSRs in; Mt <- prune(Mgt * Mt) maxIter times; the new Mt comes back in malloc()ed arrays (the caller disposes

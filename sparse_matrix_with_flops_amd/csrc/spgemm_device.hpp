@@ -1641,8 +1641,8 @@ __device__ __forceinline__ float row16_max(float v) {
   return v;
 }
 
-// pass 1: squares in place, per-row threshold and kept sum, kept count -> cnt[row]
-__global__ __launch_bounds__(256) void k_rmcl_stats(int m, const int* __restrict__ IC, float* __restrict__ C,
+// pass 1: inflate (squares, recomputed where needed, never stored), per-row threshold and kept sum, kept count -> cnt[row]
+__global__ __launch_bounds__(256) void k_rmcl_stats(int m, const int* __restrict__ IC, const float* __restrict__ C,
                                                      int* __restrict__ cnt, float* __restrict__ thresh,
                                                      float* __restrict__ ksum) {
   const int gl = threadIdx.x & 15;
@@ -1651,13 +1651,13 @@ __global__ __launch_bounds__(256) void k_rmcl_stats(int m, const int* __restrict
     const bool live = row < m;
     const int s = live ? IC[row] : 0, e = live ? IC[row + 1] : 0;
     float mx = 0.f, sum = 0.f;
-    for (int p = s + gl; p < e; p += 16) { const float v = C[p] * C[p]; C[p] = v; mx = fmaxf(mx, v); sum += v; }
+    for (int p = s + gl; p < e; p += 16) { const float v = C[p] * C[p]; mx = fmaxf(mx, v); sum += v; }   // inflate: v^2, not stored
     mx = row16_max(mx);
     sum = row16_sum(sum);
     const float th = rmcl_threshold(sum / (float)(e - s), mx);
     float ks = 0.f;
     int kc = 0;
-    for (int p = s + gl; p < e; p += 16) { const float v = C[p]; if (v >= th) { ks += v; ++kc; } }
+    for (int p = s + gl; p < e; p += 16) { const float v = C[p] * C[p]; if (v >= th) { ks += v; ++kc; } }   // the row is in L2
     ks = row16_sum(ks);
     kc = (int)row16_sum((float)kc);
     if (live && gl == 0) { cnt[row] = kc; thresh[row] = th; ksum[row] = ks; }
@@ -1679,7 +1679,8 @@ __global__ __launch_bounds__(256) void k_rmcl_compact(int m, const int* __restri
     int out = live ? newPtr[row] : 0;
     for (int p0 = s; p0 < e; p0 += 16) {
       const int p = p0 + gl;
-      const float v = p < e ? C[p] : 0.f;
+      const float c0 = p < e ? C[p] : 0.f;
+      const float v = c0 * c0;
       const bool keep = p < e && v >= th;
       const unsigned long long mk = ballot64(keep);
       const unsigned gm = (unsigned)(mk >> (lane - gl)) & 0xffffu;

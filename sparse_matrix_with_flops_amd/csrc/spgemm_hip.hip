@@ -69,7 +69,9 @@ struct DevPool {
     {
       std::lock_guard<std::mutex> lk(mu);
       auto it = free_blocks.lower_bound(r);
-      if (it != free_blocks.end() && it->first <= r + r / 4 + (size_t(2) << 20)) {
+      // best fit, and a cached block up to 4x the request is still better than a hipMalloc (tens of ms for GB-sized
+      // blocks; 288 GB of HBM make the slack affordable): R-MCL shrinks its matrices from one iteration to the next
+      if (it != free_blocks.end() && it->first <= 4 * r + (size_t(2) << 20)) {
         *p = it->second;
         live[*p] = it->first;
         cached_bytes -= it->first;
