@@ -1630,65 +1630,96 @@ __device__ __forceinline__ float rmcl_threshold(float avg, float mx) {
   return ret;
 }
 
-__device__ __forceinline__ float row16_sum(float v) {
+// reductions inside the L lanes that share a row (L = 16 or 64, aligned lane groups)
+template <int L>
+__device__ __forceinline__ float rowL_sum(float v) {
 #pragma unroll
-  for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16);
+  for (int d = L / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, L);
   return v;
 }
-__device__ __forceinline__ float row16_max(float v) {
+template <int L>
+__device__ __forceinline__ float rowL_max(float v) {
 #pragma unroll
-  for (int d = 8; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 16));
+  for (int d = L / 2; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, L));
   return v;
 }
 
-// pass 1: inflate (squares, recomputed where needed, never stored), per-row threshold and kept sum, kept count -> cnt[row]
+// pass 1: inflate (squares, recomputed where needed, never stored), per-row threshold and kept sum, kept count ->
+// cnt[row].  L lanes per row: 16 for short rows, a whole wave once rows average ~100 entries (R-MCL products do);
+// four loads in flight per lane.
+template <int L>
 __global__ __launch_bounds__(256) void k_rmcl_stats(int m, const int* __restrict__ IC, const float* __restrict__ C,
                                                      int* __restrict__ cnt, float* __restrict__ thresh,
                                                      float* __restrict__ ksum) {
-  const int gl = threadIdx.x & 15;
-  const int nrows16 = (m + 15) / 16 * 16;
-  for (int row = (blockIdx.x * 256 + threadIdx.x) >> 4; row < nrows16; row += (gridDim.x * 256) >> 4) {
+  constexpr int RPB = 256 / L;                       // rows per block
+  const int gl = threadIdx.x & (L - 1);
+  const int nrowsL = (m + RPB - 1) / RPB * RPB;
+  for (int row = blockIdx.x * RPB + threadIdx.x / L; row < nrowsL; row += gridDim.x * RPB) {
     const bool live = row < m;
     const int s = live ? IC[row] : 0, e = live ? IC[row + 1] : 0;
     float mx = 0.f, sum = 0.f;
-    for (int p = s + gl; p < e; p += 16) { const float v = C[p] * C[p]; mx = fmaxf(mx, v); sum += v; }   // inflate: v^2, not stored
-    mx = row16_max(mx);
-    sum = row16_sum(sum);
+    for (int p = s + gl; p < e; p += 4 * L) {
+      float c[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) c[i] = p + i * L < e ? C[p + i * L] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float v = c[i] * c[i]; mx = fmaxf(mx, v); sum += v; }   // inflate: v^2
+    }
+    mx = rowL_max<L>(mx);
+    sum = rowL_sum<L>(sum);
     const float th = rmcl_threshold(sum / (float)(e - s), mx);
     float ks = 0.f;
     int kc = 0;
-    for (int p = s + gl; p < e; p += 16) { const float v = C[p] * C[p]; if (v >= th) { ks += v; ++kc; } }   // the row is in L2
-    ks = row16_sum(ks);
-    kc = (int)row16_sum((float)kc);
+    for (int p = s + gl; p < e; p += 4 * L) {          // the row was just read: L2
+      float c[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) c[i] = p + i * L < e ? C[p + i * L] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float v = c[i] * c[i]; if (p + i * L < e && v >= th) { ks += v; ++kc; } }
+    }
+    ks = rowL_sum<L>(ks);
+    kc = (int)rowL_sum<L>((float)kc);
     if (live && gl == 0) { cnt[row] = kc; thresh[row] = th; ksum[row] = ks; }
   }
 }
 
 // pass 2: stable compaction of the kept entries, normalised, into the new arrays at newPtr[row]
+template <int L>
 __global__ __launch_bounds__(256) void k_rmcl_compact(int m, const int* __restrict__ IC, const int* __restrict__ JC,
                                                        const float* __restrict__ C, const int* __restrict__ newPtr,
                                                        const float* __restrict__ thresh, const float* __restrict__ ksum,
                                                        int* __restrict__ JN, float* __restrict__ CN) {
-  const int gl = threadIdx.x & 15;
+  constexpr int RPB = 256 / L;
+  const int gl = threadIdx.x & (L - 1);
   const int lane = lane_id();
-  const int nrows16 = (m + 15) / 16 * 16;
-  for (int row = (blockIdx.x * 256 + threadIdx.x) >> 4; row < nrows16; row += (gridDim.x * 256) >> 4) {
+  const int nrowsL = (m + RPB - 1) / RPB * RPB;
+  for (int row = blockIdx.x * RPB + threadIdx.x / L; row < nrowsL; row += gridDim.x * RPB) {
     const bool live = row < m;
     const int s = live ? IC[row] : 0, e = live ? IC[row + 1] : 0;
     const float th = live ? thresh[row] : 0.f, ks = live ? ksum[row] : 1.f;
     int out = live ? newPtr[row] : 0;
-    for (int p0 = s; p0 < e; p0 += 16) {
-      const int p = p0 + gl;
-      const float c0 = p < e ? C[p] : 0.f;
-      const float v = c0 * c0;
-      const bool keep = p < e && v >= th;
-      const unsigned long long mk = ballot64(keep);
-      const unsigned gm = (unsigned)(mk >> (lane - gl)) & 0xffffu;
-      if (keep) { const int o = out + __popc(gm & ((1u << gl) - 1u)); JN[o] = JC[p]; CN[o] = v / ks; }
-      out += __popc(gm);
+    for (int p0 = s; p0 < e; p0 += 2 * L) {            // two steps of L entries, their loads issued together
+      float c[2];
+      int j[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int p = p0 + i * L + gl;
+        c[i] = p < e ? C[p] : 0.f;
+        j[i] = p < e ? JC[p] : 0;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float v = c[i] * c[i];
+        const bool keep = p0 + i * L + gl < e && v >= th;
+        const unsigned long long mk = ballot64(keep);
+        const unsigned long long gm = L == 64 ? mk : ((mk >> (lane - gl)) & ((1ull << L) - 1ull));
+        if (keep) { const int o = out + __popcll(gm & ((1ull << gl) - 1ull)); JN[o] = j[i]; CN[o] = v / ks; }
+        out += __popcll(gm);
+      }
     }
   }
 }
+
 
 // self-test of the DPP scans / mask ranks against serial results computed by every lane
 __global__ void k_selftest(const int* __restrict__ in, int* __restrict__ bad) {

@@ -843,9 +843,17 @@ extern "C" int hip_rmcl_prune(spgemm_handle* h, int m, const int* dIC, const int
     return cleanup(fail(SPGEMM_ERR_HIP, "device allocation failed"));
   hipStream_t s = h->stream;
   HIPCHK(hipMemsetAsync(&h->dsmall->nnzC64, 0, sizeof(unsigned long long), s));
-  const int grid = clampi(cdiv(m, 16), 1, h->numCU * 16);
+  // lanes per row: 16 for short rows; a whole wave once rows average ~100 entries (needs nnz: one small copy)
+  int nnzIn = 0;
   if (m > 0) {
-    hipLaunchKernelGGL(k_rmcl_stats, dim3(grid), dim3(256), 0, s, m, dIC, dC, newPtr, th, ks);
+    HIPCHK(hipMemcpyAsync(&nnzIn, dIC + m, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  const bool wide = m > 0 && (long long)nnzIn >= 96ll * m;
+  const int grid = wide ? clampi(cdiv(m, 4), 1, h->numCU * 32) : clampi(cdiv(m, 16), 1, h->numCU * 16);
+  if (m > 0) {
+    if (wide) hipLaunchKernelGGL(k_rmcl_stats<64>, dim3(grid), dim3(256), 0, s, m, dIC, dC, newPtr, th, ks);
+    else hipLaunchKernelGGL(k_rmcl_stats<16>, dim3(grid), dim3(256), 0, s, m, dIC, dC, newPtr, th, ks);
     int rc = launch_scan(h, newPtr, m, &h->dsmall->nnzC64);
     if (rc) return cleanup(rc);
   } else {
@@ -859,7 +867,8 @@ extern "C" int hip_rmcl_prune(spgemm_handle* h, int m, const int* dIC, const int
       hipSuccess != pool().alloc((void**)&CN, sizeof(float) * (size_t)std::max(nz, 1)))
     return cleanup(fail(SPGEMM_ERR_HIP, "device allocation failed"));
   if (m > 0 && nz > 0) {
-    hipLaunchKernelGGL(k_rmcl_compact, dim3(grid), dim3(256), 0, s, m, dIC, dJC, dC, newPtr, th, ks, JN, CN);
+    if (wide) hipLaunchKernelGGL(k_rmcl_compact<64>, dim3(grid), dim3(256), 0, s, m, dIC, dJC, dC, newPtr, th, ks, JN, CN);
+    else hipLaunchKernelGGL(k_rmcl_compact<16>, dim3(grid), dim3(256), 0, s, m, dIC, dJC, dC, newPtr, th, ks, JN, CN);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(s));
