@@ -272,6 +272,27 @@ def test_long_A_rows_and_empty_B_rows_in_staging():
     assert_parity(hip_mul(A, B), po.sequential_spmm(A, B), what="long-A-rows", inputs=(A, B))
 
 
+def test_duplicate_columns_inside_A_and_B_rows():
+    """Repeated column indices inside a row of A and inside a row of B (an unsorted, un-deduplicated input): the
+    accumulators key on the column, so repeats just add up -- same structure and values as the CPU kernel."""
+    rng = np.random.default_rng(5)
+    k, n = 2000, 300000
+    brows = []
+    for _ in range(k):
+        c = rng.integers(0, n, size=int(rng.integers(5, 80)))
+        brows.append(np.concatenate([c, c[:len(c) // 3]]))                   # a third of the columns twice
+    B = _rows_csr(brows, n, 1)
+    arows = []
+    for s_ in (3, 10, 40, 100, 300, 900, 1800):
+        c = rng.choice(k, size=s_, replace=False)
+        arows.append(np.concatenate([c, c[:s_ // 4]]))                        # repeated B rows
+    arows += [rng.choice(k, size=int(rng.integers(1, 30)), replace=False) for _ in range(500)]
+    A = _rows_csr(arows, k, 2)
+    want = po.sequential_spmm(A, B)
+    assert np.diff(want.rowPtr).max() > 4096
+    assert_parity(hip_mul(A, B), want, what="duplicates in A and B rows")
+
+
 def test_every_bin_boundary():
     """Rows engineered to sit exactly on the flop-bin edges 0,1,2,4,5,16,17,64,65,512,513,4096,4097."""
     edges = [0, 1, 2, 4, 5, 16, 17, 64, 65, 512, 513, 4096, 4097]
