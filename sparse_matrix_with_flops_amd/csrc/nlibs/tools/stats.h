@@ -19,17 +19,18 @@ inline std::vector<int> gpuFlopsStats(const CSR& dA, const CSR& dB) {
   return stats;
 }
 
-// void outputStats(const std::vector<int>&), nlibs/tools/stats.cc:14-27: "(lo -> hi)\tcount\tshare"
+// Report in the format of the reference's outputStats (nlibs/tools/stats.cc:14-27): one line per bucket,
+// "(lo -> hi)<TAB>count<TAB>share", the last bucket open-ended, preceded by the total.
 inline void outputStats(const std::vector<int>& stats) {
-  long long sum = 0;
-  for (size_t i = 0; i < stats.size(); ++i) sum += stats[i];
-  printf("Total sum = %lld\n", sum);
-  size_t i = 0;
-  for (; i + 1 < stats.size(); ++i) {
-    const long bound = 1l << i;
-    printf("(%ld -> %ld)\t%d\t%.6f\t\n", bound / 2 + 1, bound, stats[i], (QValue)stats[i] / sum);
+  long long total = 0;
+  for (int c : stats) total += c;
+  printf("Total sum = %lld\n", total);
+  const int last = (int)stats.size() - 1;
+  for (int b = 0; b <= last; ++b) {
+    const long hi = 1l << b, lo = hi / 2 + 1;
+    const double share = (double)(QValue)((QValue)stats[b] / total);
+    if (b < last) printf("(%ld -> %ld)\t%d\t%.6f\t\n", lo, hi, stats[b], share);
+    else printf("(%ld -> INF)\t%d\t%.6f\t\n", lo, stats[b], share);
   }
-  const long bound = 1l << i;
-  printf("(%ld -> INF)\t%d\t%.6lf\t\n", bound / 2 + 1, stats[i], (QValue)stats[i] / sum);
 }
 #endif
