@@ -23,8 +23,19 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace smf {
+
+#ifdef SMF_ABLATE
+// diagnostic build only (make ablate): pieces of the wave-per-row numeric kernel can be switched off at run time
+// (SPGEMM_ABLATE bit mask: 1 no insert, 2 no gathers, 4 no compaction, 8 no walk) to see what its time is made of.
+// The results are wrong by construction; never the product.
+__device__ int g_ablate = 0;
+#define ABL(bit) (g_ablate & (bit))
+#else
+#define ABL(bit) 0
+#endif
 
 constexpr int WAVE = 64;
 constexpr int NBINS = 9;  // {0 | 1 | 2-4 | 5-16 | 17-64 | 65-512 | 513-2048 | 2049-4096 | >4096}
@@ -167,7 +178,11 @@ __device__ __forceinline__ int hash_insert(int* keys, int size, int shift, int c
 // instructions each per round to turn back into lane masks; these kernels are VALU-bound.)  Conditions used inside
 // one round stay lane masks in SGPRs and combine on the scalar unit.
 // Returns the number of new keys of the whole WAVE (uniform).
-template <int U, bool POW2 = true>
+// The dummy words are initialised to DUMMY_KEY (never EMPTY_KEY, never a column), so a CAS that lands there fails
+// and a parked lane needs no masking when the new keys of a round are counted.
+constexpr int DUMMY_KEY = (int)0x80000000;
+
+template <bool POW2 = true, int U>
 __device__ __forceinline__ int hash_insert_multi(int* keys, int size, int shift, const bool (&act)[U],
                                                  const int (&col)[U], int* dummy, int* err) {
   char* const base = reinterpret_cast<char*>(keys);
@@ -181,27 +196,25 @@ __device__ __forceinline__ int hash_insert_multi(int* keys, int size, int shift,
     const unsigned h = POW2 ? hv >> shift : __umulhi(hv, (unsigned)size);
     hB[u] = act[u] ? (int)(h * 4u) : dumB;
   }
-  bool done = false;
   int probe = 0;
-  do {                                              // at least one round: nothing between the gathers and their use
+  for (;;) {                                        // first round unconditional: nothing between the gathers and their use
     int old[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) old[u] = atomicCAS(reinterpret_cast<int*>(base + hB[u]), EMPTY_KEY, col[u]);
-    bool more = false;
+    ++probe;
+    unsigned long long anyPend = 0ull;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool pend = hB[u] != dumB;
-      const bool fresh = pend && old[u] == EMPTY_KEY;
-      const bool adv = pend && !fresh && old[u] != col[u];
-      claimed += __popcll(ballot64(fresh));
+      claimed += __popcll(ballot64(old[u] == EMPTY_KEY));                  // the dummy is never EMPTY_KEY
+      const bool adv = hB[u] != dumB && old[u] != EMPTY_KEY && old[u] != col[u];
       // power-of-two tables: triangular steps (+1, +2, +3, ...) visit every slot once and break up probe clusters
-      const int nh = POW2 ? ((hB[u] + (probe + 1) * 4) & maskB) : (hB[u] + 4 == size * 4 ? 0 : hB[u] + 4);
+      const int nh = POW2 ? ((hB[u] + probe * 4) & maskB) : (hB[u] + 4 == size * 4 ? 0 : hB[u] + 4);
       hB[u] = adv ? nh : dumB;
-      more = more || adv;
+      anyPend |= ballot64(hB[u] != dumB);                                  // a plain compare: stays a lane mask
     }
-    done = ballot64(more) == 0ull;
-  } while (++probe < size && !done);
-  if (!done) atomicOr(err, ERRF_TABLE_FULL);
+    if (anyPend == 0ull) break;
+    if (probe >= size) { atomicOr(err, ERRF_TABLE_FULL); break; }
+  }
   return claimed;
 }
 
@@ -215,6 +228,7 @@ __device__ __forceinline__ int hash_insert_multi(int* keys, int size, int shift,
 // ------------------------------------------------------------------------------------------------
 typedef unsigned long long slot_t;                       // low half: key (column), high half: value bits
 constexpr slot_t EMPTY_SLOT = 0x00000000FFFFFFFFull;      // {EMPTY_KEY, 0.0f}
+constexpr slot_t DUMMY_SLOT = 0x0000000080000000ull;      // {DUMMY_KEY, 0.0f}: what the dummy words hold
 __device__ __forceinline__ slot_t make_slot(int col, float v) {
   return (slot_t)(unsigned)col | ((slot_t)__float_as_uint(v) << 32);
 }
@@ -238,7 +252,7 @@ __device__ __forceinline__ void hash_accum(slot_t* tab, int size, int shift, int
 
 // U products per lane in lock step, wave-uniform control flow.  Lanes without work aim their CAS at a private
 // 8-byte dummy (a CAS costs the same with any lane count; the float add below does not, hence its EXEC mask).
-template <int U, bool POW2 = true>
+template <bool POW2 = true, int U>
 __device__ __forceinline__ void hash_accum_multi(slot_t* tab, int size, int shift, const bool (&act)[U],
                                                  const int (&col)[U], const float (&val)[U], slot_t* dummy, int* err) {
   char* const base = reinterpret_cast<char*>(tab);
@@ -256,28 +270,28 @@ __device__ __forceinline__ void hash_accum_multi(slot_t* tab, int size, int shif
     dupB[u] = dumB;
     mine[u] = make_slot(col[u], val[u]);
   }
-  bool done = false;
   int probe = 0;
-  do {                                              // at least one round: the col and value gathers stay together
+  for (;;) {                                        // first round unconditional: the col and value gathers stay together
     slot_t old[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) old[u] = atomicCAS(reinterpret_cast<slot_t*>(base + hB[u]), EMPTY_SLOT, mine[u]);
-    bool more = false;
+    ++probe;
+    unsigned long long anyPend = 0ull;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool pend = hB[u] != dumB;
       const bool same = pend && slot_key(old[u]) == col[u];
-      const bool adv = pend && !same && old[u] != EMPTY_SLOT;
+      const bool adv = pend && old[u] != EMPTY_SLOT && slot_key(old[u]) != col[u];
       dupB[u] = same ? hB[u] : dupB[u];
       int nh;
-      if (POW2) nh = (hB[u] + (probe + 1) * 8) & maskB;     // triangular steps
+      if (POW2) nh = (hB[u] + probe * 8) & maskB;            // triangular steps
       else { nh = hB[u] + stepB[u]; nh = nh >= sizeB ? nh - sizeB : nh; }
       hB[u] = adv ? nh : dumB;
-      more = more || adv;
+      anyPend |= ballot64(hB[u] != dumB);
     }
-    done = ballot64(more) == 0ull;
-  } while (++probe < size && !done);
-  if (!done) atomicOr(err, ERRF_TABLE_FULL);
+    if (anyPend == 0ull) break;
+    if (probe >= size) { atomicOr(err, ERRF_TABLE_FULL); break; }
+  }
 #pragma unroll
   for (int u = 0; u < U; ++u)
     if (dupB[u] != dumB) atomicAdd(reinterpret_cast<float*>(base + dupB[u] + 4), val[u]);
@@ -497,6 +511,18 @@ __global__ __launch_bounds__(K1_THREADS) void k_scatter_rows(int m, const unsign
   }
 }
 
+// Launch grids of the statically scheduled kernels are multiples of 8 (host: grid8()).
+struct XcdRange { int lo, hi, bi, nb; };
+__device__ __forceinline__ XcdRange xcd_range(int count) {
+  const int x = blockIdx.x & 7;
+  XcdRange r;
+  r.bi = blockIdx.x >> 3;
+  r.nb = gridDim.x >> 3;
+  r.lo = (int)((long long)count * x >> 3);
+  r.hi = (int)((long long)count * (x + 1) >> 3);
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Small rows (<= 64 products): a group of G lanes per row, A entries one after the other, the G
 // lanes stride the (short, bounded by the bin) B row.  Tables live in LDS, one per group, sized per
@@ -514,7 +540,10 @@ __global__ __launch_bounds__(256) void k_sym_small(const int* __restrict__ binPt
   const int tid = threadIdx.x, g = tid / G, gl = tid % G;
   const int first = binPtr[binLo], count = binPtr[binHi] - first;
   const int iters = (count + GROUPS - 1) / GROUPS;   // uniform trip count per block
-  for (int it = blockIdx.x; it < iters; it += gridDim.x) {
+  // XCD-contiguous schedule: the blocks that share an XCD (blockIdx % 8, guide "Workgroup dispatch") walk ONE contiguous
+  // eighth of the bin, so that the B rows its A rows have in common are fetched into that XCD's L2 once, not into all eight
+  const XcdRange xr = xcd_range(iters);
+  for (int it = xr.lo + xr.bi; it < xr.hi; it += xr.nb) {
     const int q = it * GROUPS + g;
     const bool live = q < count;
     const int row = live ? rowIds[first + q] : 0;
@@ -559,7 +588,10 @@ __global__ __launch_bounds__(256) void k_num_small(const int* __restrict__ binPt
   const int tid = threadIdx.x, g = tid / G, gl = tid % G;
   const int first = binPtr[binLo], count = binPtr[binHi] - first;
   const int iters = (count + GROUPS - 1) / GROUPS;
-  for (int it = blockIdx.x; it < iters; it += gridDim.x) {
+  // XCD-contiguous schedule: the blocks that share an XCD (blockIdx % 8, guide "Workgroup dispatch") walk ONE contiguous
+  // eighth of the bin, so that the B rows its A rows have in common are fetched into that XCD's L2 once, not into all eight
+  const XcdRange xr = xcd_range(iters);
+  for (int it = xr.lo + xr.bi; it < xr.hi; it += xr.nb) {
     const int q = it * GROUPS + g;
     const bool live = q < count;
     const int row = live ? rowIds[first + q] : 0;
@@ -596,23 +628,6 @@ __global__ __launch_bounds__(256) void k_num_small(const int* __restrict__ binPt
     wave_lds_sync();
   }
 }
-
-// ---- diagnostic build only (-DSMF_STAMPS): per-phase cycle sums, written by wave 0 lane 0 of every block into
-// a debug buffer that nothing else reads (guide §7 "In-kernel stamps").  Never compiled into the product.
-#ifdef SMF_STAMPS
-__device__ unsigned long long g_stamps[4][16];
-#define STAMP_DECL unsigned long long st_t0 = __builtin_readcyclecounter(), st_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}
-#define STAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_t0; st_t0 = t_; } while (0)
-#define STAMP_FLUSH(k) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_stamps[k][i_], st_acc[i_]); } while (0)
-#define STAMP_PARAMS , unsigned long long& st_t0, unsigned long long* st_acc
-#define STAMP_ARGS , st_t0, st_acc
-#else
-#define STAMP_DECL
-#define STAMP(i)
-#define STAMP_FLUSH(k)
-#define STAMP_PARAMS
-#define STAMP_ARGS
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // Rows with 17..64 products: 16 lanes per row (4 rows per wave), products flattened over the 16 lanes.
@@ -695,7 +710,10 @@ __global__ __launch_bounds__(256) void k_sym_g16(const int* __restrict__ binPtr,
   const int tid = threadIdx.x, g = tid >> 4, gl = tid & 15;
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
   const int iters = (count + 15) / 16;
-  for (int it = blockIdx.x; it < iters; it += gridDim.x) {
+  // XCD-contiguous schedule: the blocks that share an XCD (blockIdx % 8, guide "Workgroup dispatch") walk ONE contiguous
+  // eighth of the bin, so that the B rows its A rows have in common are fetched into that XCD's L2 once, not into all eight
+  const XcdRange xr = xcd_range(iters);
+  for (int it = xr.lo + xr.bi; it < xr.hi; it += xr.nb) {
     const int q = it * 16 + g;
     const bool live = q < count;
     const int row = live ? rowIds[first + q] : 0;
@@ -734,7 +752,10 @@ __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr,
   const int tid = threadIdx.x, g = tid >> 4, gl = tid & 15;
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
   const int iters = (count + 15) / 16;
-  for (int it = blockIdx.x; it < iters; it += gridDim.x) {
+  // XCD-contiguous schedule: the blocks that share an XCD (blockIdx % 8, guide "Workgroup dispatch") walk ONE contiguous
+  // eighth of the bin, so that the B rows its A rows have in common are fetched into that XCD's L2 once, not into all eight
+  const XcdRange xr = xcd_range(iters);
+  for (int it = xr.lo + xr.bi; it < xr.hi; it += xr.nb) {
     const int q = it * 16 + g;
     const bool live = q < count;
     const int row = live ? rowIds[first + q] : 0;
@@ -766,162 +787,261 @@ __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Flattened product walk of ONE C row by a block of NW waves.
-// A entries are staged in LDS in chunks of 64*NW (one per thread) together with the inclusive scan
-// of their B-row lengths; the staged arrays are read-only until the next chunk.  Every wave then takes
-// rounds of 64 consecutive products, U rounds per trip so that U gathers of B are in flight per wave.
-// A lane finds the A entry that owns its product with a branch-free binary search over the scan in LDS
-// (log2(64*NW) dependent ds_reads, the U searches of a trip interleave): no ballots, no fences, no
-// divergence in the walk.  f(act[U], col[U], val[U]) is called in wave-uniform control flow (val = a*b).
+// Product walk of ONE C row by a block of NW waves.
+//
+// The row's A entries are staged in groups of 64 (one per lane of the staging wave).  A group splits in two:
+//   * entries whose B row has >= LONG_LEN entries ("long": 3 % of the entries, 55-65 % of the products of a power-law
+//     matrix) are walked directly: a unit of 64*U consecutive products of ONE B row per wave -- no search, the A value
+//     and the B-row base are wave-uniform, the gathers are fully coalesced;
+//   * the other entries are flattened: the group's <= 64*63 products are numbered consecutively, a lane finds the entry
+//     that owns its product from OWNERSHIP MARKS: bit p of the group's mark words is set when product p is the last one
+//     of its entry, so owner(p) = (entries that end before this 64-product round) + popcount(marks below the lane)
+//     -- one v_mbcnt pair instead of a six-step binary search through LDS.
+// NW > 1: every wave stages one group (no cross-wave scan), one barrier, then the waves take UNITS (a trip of U rounds of
+// some group's short products, or 64*U products of a long entry) from one list: the first NW units are dealt, the rest
+// claimed from an LDS counter (probe chains make unit times uneven).  f(act[U], col[U], val[U]) is called in wave-uniform
+// control flow (val = a*b).
 // ------------------------------------------------------------------------------------------------
-template <int NW, int U>
-struct RowStage {
-  int incl[WAVE * NW];     // inclusive scan of B-row lengths of the staged A entries (T beyond the row)
-  int off[WAVE * NW];      // IB[j] - exclusive scan: product p of the chunk lives at JB[off + p]
-  float aval[WAVE * NW];
-  int wsum[NW];
-  int trip;                // next unclaimed trip of the staged chunk (NW > 1: waves claim trips as they finish)
-  slot_t dummy[WAVE * NW]; // one private 8-byte word per lane: target of predicated-off atomics
-};
+constexpr int LONG_LEN = WAVE;           // B rows of at least this length are walked by whole waves
 
 // first chunk of A entries fetched ahead of time (wave-per-row kernels prefetch the next row's while they work)
 struct PreA { int j; float a; bool valid; };
 
-template <int NW, int U, bool NEED_VAL, class F>
-__device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, int ae,
-                                                 const int* __restrict__ JA, const float* __restrict__ VA,
-                                                 const int* __restrict__ IB, const int* __restrict__ JB,
-                                                 const float* __restrict__ VB, F&& f, PreA pre STAMP_PARAMS) {
-  constexpr int K = WAVE * NW;
-  const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
-  for (int chunk = as; chunk < ae; chunk += K) {
-    // ---- stage
-    const int ap = chunk + tid;
-    int len = 0, bs = 0;
-    float a = 0.f;
-    if (ap < ae) {
-      const bool usePre = pre.valid && chunk == as;
-      const int j = usePre ? pre.j : JA[ap];
-      bs = IB[j];
-      len = IB[j + 1] - bs;
-      if (NEED_VAL) a = usePre ? pre.a : VA[ap];
+struct WalkStage1 {                      // one wave per row
+  unsigned long long marks[WAVE];        // ownership marks of the staged group (64 entries x <= 63 products)
+  int2 rec[WAVE];                        // short entries, compacted: {JB offset of product 0 of the group's numbering, a}
+  slot_t dummy[WAVE];                    // one 8-byte word per lane: target of predicated-off atomics
+};
+template <int NW>
+struct WalkStageN {
+  unsigned long long marks[NW][WAVE];
+  int4 rec[NW][WAVE];                    // short entries from the bottom {off, a, -, -}; long ones from the top {bs, a, len, unit offset}
+  unsigned char wpre[NW][WAVE];          // entries of the group that end before round r
+  int gT[NW], gNS[NW], gNL[NW], gLU[NW]; // per group: short products, short entries, long entries, long units
+  int claim;                             // next unclaimed unit of the chunk
+  slot_t dummy[WAVE];                    // shared by the waves: whatever lands there is never read
+};
+template <int NW> struct WalkSel { typedef WalkStageN<NW> type; };
+template <> struct WalkSel<1> { typedef WalkStage1 type; };
+
+struct GroupLanes {                      // what the staging wave keeps in registers about its group
+  int bs, len;                           // this lane's entry: B-row start and length
+  float a;
+  int T, ns;                             // short products / short entries of the group (uniform)
+  unsigned long long lmask;              // lanes holding a long entry
+  unsigned long long mw;                 // mark word `lane`
+  int pexcl;                             // short entries that end before round `lane`
+};
+
+template <bool NEED_VAL, int RS, int LONGLEN>
+__device__ __forceinline__ GroupLanes stage_group(unsigned long long* marks, char* rec, int ap, int ae,
+                                                  const int* __restrict__ JA, const float* __restrict__ VA,
+                                                  const int* __restrict__ IB, PreA pre) {
+  const int lane = lane_id();
+  GroupLanes g;
+  g.bs = 0; g.len = 0; g.a = 0.f;
+  if (ap < ae) {
+    const int j = pre.valid ? pre.j : JA[ap];
+    g.bs = IB[j];
+    g.len = max(IB[j + 1] - g.bs, 0);
+    if (NEED_VAL) g.a = pre.valid ? pre.a : VA[ap];
+  }
+  const bool isLong = g.len >= LONGLEN;
+  const int slen = isLong ? 0 : g.len;
+  const bool keep = slen > 0;
+  const unsigned long long km = ballot64(keep);
+  g.lmask = ballot64(isLong);
+  const int incl = wave_incl_add(slen);
+  g.T = __builtin_amdgcn_readlane(incl, 63);
+  g.ns = __popcll(km);
+  marks[lane] = 0ull;
+  wave_lds_sync();
+  if (keep) {
+    *reinterpret_cast<int2*>(rec + mask_rank(km) * RS) = make_int2(g.bs - (incl - slen), __float_as_int(g.a));
+    const int q = incl - 1;                              // last product of this entry
+    if (q < WAVE * WAVE) atomicOr(reinterpret_cast<unsigned*>(marks) + (q >> 5), 1u << (q & 31));
+  }
+  wave_lds_sync();
+  g.mw = marks[lane];
+  const int pc = __popcll(g.mw);
+  g.pexcl = wave_incl_add(pc) - pc;
+  return g;
+}
+
+// U rounds of 64 short products of one staged group.  W[u] / base[u]: mark word and entries-before of round r0+u
+// (wave-uniform values, in SGPRs or broadcast VGPRs).
+template <int U, bool NEED_VAL, int RS, class F>
+__device__ __forceinline__ void short_trip(const char* rec, int T, int ns, int r0, const unsigned long long (&W)[U],
+                                           const int (&base)[U], const int* __restrict__ JB,
+                                           const float* __restrict__ VB, F&& f) {
+  const int lane = lane_id();
+  int col[U];
+  float av[U], vb[U], val[U];
+  bool act[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {                          // straight-line, no branches around the gathers
+    const int p0 = (r0 + u) * WAVE + lane;
+    act[u] = p0 < T;
+    const int p = min(p0, T - 1);                        // lanes past the end shadow the last product: valid, nearby reads
+    int e = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(W[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)W[u], (unsigned)base[u]));
+    e = min(e, ns - 1);
+    const int2 ra = *reinterpret_cast<const int2*>(rec + e * RS);
+    const int jb = ra.x + p;
+    if (ABL(2)) { col[u] = jb; vb[u] = 1.f; }
+    else {
+    col[u] = JB[jb];
+    vb[u] = NEED_VAL ? VB[jb] : 0.f;
     }
-    int incl = wave_incl_add(len);
-    if (NW > 1) {
-      if (lane == 63) st.wsum[w] = incl;
-      __syncthreads();
-      int woff = 0;
-      for (int i = 0; i < w; ++i) woff += st.wsum[i];
-      incl += woff;
-    }
-    st.incl[tid] = incl;
-    st.off[tid] = bs - (incl - len);
-    if (NEED_VAL) st.aval[tid] = a;
-    if (NW > 1 && tid == 0) st.trip = NW;
-    __syncthreads();
-    STAMP(8);
-    const int T = st.incl[K - 1];
-    const int nrounds = (T + WAVE - 1) / WAVE;
-    // boundaries between the 64-entry groups: lane i holds the end of group i.  A round's 64 consecutive products
-    // almost always fall into one group, found with two ballots; the top log2(NW) search levels disappear
-    int bv = 0x7fffffff;
-    if (NW > 1 && lane < NW - 1) bv = st.incl[lane * WAVE + WAVE - 1];
-    // ---- trips of U consecutive rounds (64*U products).  The first NW trips are dealt out, the rest are claimed
-    // from an LDS counter as waves finish: probe chains make trip times uneven and the chunk ends on a barrier
-    const int ntrips = (nrounds + U - 1) / U;
-    for (int t = __builtin_amdgcn_readfirstlane(w); t < ntrips;) {   // t is wave-uniform: keep its arithmetic scalar
-      int tnext = t + 1;
-      if (NW > 1) { tnext = 0; if (lane == 0) tnext = atomicAdd(&st.trip, 1); }
-      int p[U], e[U];
-      bool act[U];
+    av[u] = __int_as_float(ra.y);
+  }
+  __builtin_amdgcn_sched_barrier(0);                     // all 2U gathers are issued before the first of them is waited for
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int p0 = (t * U + u) * WAVE;
-        act[u] = p0 + lane < T;
-        p[u] = min(p0 + lane, T - 1);                // lanes past the end shadow the last product: valid, nearby reads
-        int grp = 0;
-        if (NW > 1) {
-          // (clamped like p[u]: a round past the end of the chunk must land in the group of the last product,
-          // whose entry is real -- the padding entries behind the row have no B row to read from)
-          const int g0 = __popcll(ballot64(bv <= min(p0, T - 1)));
-          const int g1 = __popcll(ballot64(bv <= min(p0 + (WAVE - 1), T - 1)));
-          grp = g0;
-          if (g0 != g1) {                            // the round straddles a group boundary (about 1 in 16)
-            for (int i = g0; i < g1; ++i) grp += st.incl[i * WAVE + WAVE - 1] <= p[u] ? 1 : 0;
-          }
-        }
-        e[u] = grp * WAVE * 4;                       // byte offset into the staged arrays
-      }
-      // first entry with incl > p inside the group, all U searches in lock step.  Offsets stay in bytes, so a step
-      // is add + ds_read(offset) + compare + select (the kernels are VALU-bound: instruction count is time)
-      const char* inclB = reinterpret_cast<const char*>(st.incl);
+  for (int u = 0; u < U; ++u) val[u] = av[u] * vb[u];
+  f(act, col, val);
+}
+
+// 64*U consecutive products [s0, s0 + 64U) of one long B row: base, length and A value are wave-uniform
+template <int U, bool NEED_VAL, class F>
+__device__ __forceinline__ void long_trip(int kb, int kl, float ka, int s0, const int* __restrict__ JB,
+                                          const float* __restrict__ VB, F&& f) {
+  const int lane = lane_id();
+  int col[U];
+  float vb[U], val[U];
+  bool act[U];
 #pragma unroll
-      for (int sft = WAVE / 2; sft >= 1; sft >>= 1) {
+  for (int u = 0; u < U; ++u) {
+    const int p0 = s0 + u * WAVE + lane;
+    act[u] = p0 < kl;
+    const int jb = kb + min(p0, kl - 1);
+    col[u] = JB[jb];
+    vb[u] = NEED_VAL ? VB[jb] : 0.f;
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int c = e[u] + sft * 4;
-          e[u] = *reinterpret_cast<const int*>(inclB + c - 4) <= p[u] ? c : e[u];
-        }
-      }
-      int col[U];
-      float val[U];
-#ifdef SMF_STAMPS
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      STAMP(5);                                   // search done
-#endif
-      float av[U], vb[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {                // straight-line, no branches around the gathers
-        const int jb = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(st.off) + e[u]) + p[u];
-        col[u] = JB[jb];
-        vb[u] = NEED_VAL ? VB[jb] : 0.f;
-        av[u] = NEED_VAL ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(st.aval) + e[u]) : 0.f;
-      }
-      __builtin_amdgcn_sched_barrier(0);           // all 2U gathers are issued before the first of them is waited for
-#pragma unroll
-      for (int u = 0; u < U; ++u) val[u] = av[u] * vb[u];
-#ifdef SMF_STAMPS
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      STAMP(6);                                   // gather landed
-#endif
-      f(act, col, val);
-#ifdef SMF_STAMPS
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      STAMP(9);                                   // insert done
-#endif
-      t = NW > 1 ? __builtin_amdgcn_readfirstlane(tnext) : tnext;
-    }
-    STAMP(7);
-    __syncthreads();
-    STAMP(10);
+  for (int u = 0; u < U; ++u) val[u] = ka * vb[u];
+  f(act, col, val);
+}
+
+// wave-uniform R in 1..8 -> compile-time round count (5 runs as 6, 7 as 8): a trip costs what its rounds cost
+template <class G>
+__device__ __forceinline__ void with_rounds(int R, G&& g) {
+  switch (R) {
+    case 1: g(std::integral_constant<int, 1>{}); break;
+    case 2: g(std::integral_constant<int, 2>{}); break;
+    case 3: g(std::integral_constant<int, 3>{}); break;
+    case 4: g(std::integral_constant<int, 4>{}); break;
+    case 5: case 6: g(std::integral_constant<int, 6>{}); break;
+    default: g(std::integral_constant<int, 8>{}); break;
   }
 }
 
-// call sites without a prefetched chunk
+// ---- one wave per row (rows of at most 512 products): no long path, the whole group is flattened and ALL its rounds
+// are gathered before the first insert -- one memory round trip and one probe sequence per group instead of one per
+// pair of rounds (these kernels are bound by the chain of dependent waits of a wave, not by any unit's throughput).
+// f is a generic callable: f(act[R], col[R], val[R]) for R in {1,2,3,4,6,8}.
 template <int NW, int U, bool NEED_VAL, class F>
-__device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, int ae, const int* __restrict__ JA,
-                                                 const float* __restrict__ VA, const int* __restrict__ IB,
-                                                 const int* __restrict__ JB, const float* __restrict__ VB, F&& f STAMP_PARAMS) {
-  for_each_product<NW, U, NEED_VAL>(st, as, ae, JA, VA, IB, JB, VB, f, PreA{0, 0.f, false} STAMP_ARGS);
+__device__ __forceinline__ typename std::enable_if<NW == 1>::type
+for_each_product(WalkStage1& st, int as, int ae, const int* __restrict__ JA, const float* __restrict__ VA,
+                 const int* __restrict__ IB, const int* __restrict__ JB, const float* __restrict__ VB, F&& f,
+                 PreA pre = PreA{0, 0.f, false}, int* err = nullptr) {
+  const int lane = lane_id();
+  for (int gb = as; gb < ae; gb += WAVE) {
+    const GroupLanes g = stage_group<NEED_VAL, 8, 0x40000000>(st.marks, reinterpret_cast<char*>(st.rec), gb + lane, ae, JA, VA, IB,
+                                                              gb == as ? pre : PreA{0, 0.f, false});
+    if (g.T > WAVE * WAVE) {                             // cannot happen for rows of this bin (<= 512 products)
+      if (err && lane == 0) atomicOr(err, ERRF_TABLE_FULL);
+      continue;
+    }
+    const int nr = (g.T + WAVE - 1) >> 6;
+    const unsigned mlo = (unsigned)g.mw, mhi = (unsigned)(g.mw >> 32);
+    for (int r0 = 0; r0 < nr; r0 += 8) {
+      with_rounds(min(8, nr - r0), [&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        unsigned long long W[R];
+        int base[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          const int r = min(r0 + u, WAVE - 1);
+          W[u] = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mlo, r) |
+                 ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mhi, r) << 32);
+          base[u] = __builtin_amdgcn_readlane(g.pexcl, r);
+        }
+        short_trip<R, NEED_VAL, 8>(reinterpret_cast<const char*>(st.rec), g.T, g.ns, r0, W, base, JB, VB, f);
+      });
+    }
+  }
 }
 
-#ifdef SMF_STAMPS
-// un-instrumented call sites of the diagnostic build
+// ---- NW waves per row
 template <int NW, int U, bool NEED_VAL, class F>
-__device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, int ae, const int* __restrict__ JA,
-                                                 const float* __restrict__ VA, const int* __restrict__ IB,
-                                                 const int* __restrict__ JB, const float* __restrict__ VB, F&& f) {
-  unsigned long long t0 = 0, acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
-  for_each_product<NW, U, NEED_VAL>(st, as, ae, JA, VA, IB, JB, VB, f, PreA{0, 0.f, false}, t0, acc);
+__device__ __forceinline__ typename std::enable_if<(NW > 1)>::type
+for_each_product(WalkStageN<NW>& st, int as, int ae, const int* __restrict__ JA, const float* __restrict__ VA,
+                 const int* __restrict__ IB, const int* __restrict__ JB, const float* __restrict__ VB, F&& f,
+                 PreA pre = PreA{0, 0.f, false}, int* err = nullptr) {
+  (void)err;
+  static_assert(NW <= 16, "the unit table of a chunk lives in the first 16 lanes");
+  constexpr int K = WAVE * NW;
+  constexpr int UP = WAVE * U;                           // products per unit
+  const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+  (void)pre;
+  for (int chunk = as; chunk < ae; chunk += K) {
+    // ---- wave w stages group w of the chunk
+    {
+      const GroupLanes g = stage_group<NEED_VAL, 16, LONG_LEN>(st.marks[w], reinterpret_cast<char*>(st.rec[w]), chunk + tid, ae, JA, VA,
+                                                     IB, PreA{0, 0.f, false});
+      const bool isLong = (g.lmask >> lane) & 1ull;
+      const int units = isLong ? (g.len + UP - 1) / UP : 0;
+      const int uincl = wave_incl_add(units);
+      if (isLong) st.rec[w][WAVE - 1 - mask_rank(g.lmask)] = make_int4(g.bs, __float_as_int(g.a), g.len, uincl - units);
+      st.wpre[w][lane] = (unsigned char)g.pexcl;
+      if (lane == 0) { st.gT[w] = g.T; st.gNS[w] = g.ns; st.gNL[w] = __popcll(g.lmask); }
+      if (lane == 63) st.gLU[w] = uincl;
+      if (tid == 0) st.claim = NW;
+    }
+    __syncthreads();
+    // ---- the chunk's unit list: short trips of the groups first, then the long units (lane g < NW holds group g)
+    const int gT = lane < NW ? st.gT[lane] : 0;
+    const int gNS = lane < NW ? st.gNS[lane] : 0;
+    const int gNL = lane < NW ? st.gNL[lane] : 0;
+    const int lug = lane < NW ? st.gLU[lane] : 0;
+    const int ntg = (((gT + WAVE - 1) >> 6) + U - 1) / U;
+    const int sIncl = wave_incl_add(ntg), lIncl = wave_incl_add(lug);
+    const int S = __builtin_amdgcn_readlane(sIncl, 63);
+    const int total = S + __builtin_amdgcn_readlane(lIncl, 63);
+    for (int u = __builtin_amdgcn_readfirstlane(w); u < total;) {
+      int unext = 0;
+      if (lane == 0) unext = atomicAdd(&st.claim, 1);
+      if (u < S) {
+        const int g = __popcll(ballot64(sIncl <= u));                       // group of this trip (< NW: sIncl[63] = S > u)
+        const int t = u - (__builtin_amdgcn_readlane(sIncl, g) - __builtin_amdgcn_readlane(ntg, g));
+        const int T = __builtin_amdgcn_readlane(gT, g), ns = __builtin_amdgcn_readlane(gNS, g);
+        unsigned long long W[U];
+        int base[U];
+#pragma unroll
+        for (int uu = 0; uu < U; ++uu) {
+          const int r = min(t * U + uu, WAVE - 1);
+          W[uu] = st.marks[g][r];                                          // uniform address: broadcast reads
+          base[uu] = st.wpre[g][r];
+        }
+        short_trip<U, NEED_VAL, 16>(reinterpret_cast<const char*>(st.rec[g]), T, ns, t * U, W, base, JB, VB, f);
+      } else {
+        const int ul = u - S;
+        const int g = __popcll(ballot64(lIncl <= ul));
+        const int ug = ul - (__builtin_amdgcn_readlane(lIncl, g) - __builtin_amdgcn_readlane(lug, g));
+        const int nl = __builtin_amdgcn_readlane(gNL, g);
+        const int uex = lane < nl ? st.rec[g][WAVE - 1 - lane].w : 0x7fffffff;   // unit offsets of the group's long entries
+        const int k = __popcll(ballot64(uex <= ug)) - 1;
+        const int4 r4 = st.rec[g][WAVE - 1 - k];
+        long_trip<U, NEED_VAL>(r4.x, r4.z, __int_as_float(r4.y), (ug - r4.w) * UP, JB, VB, f);
+      }
+      u = __builtin_amdgcn_readfirstlane(unext);
+    }
+    // the callback's last LDS atomics return nothing (ds_or / ds_add_f32): nothing else waits for them, and a wave
+    // that leaves the barrier may read their target before they have landed (seen as lost bitmap bits)
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
+    __syncthreads();
+  }
 }
-template <int NW, int U, bool NEED_VAL, class F>
-__device__ __forceinline__ void for_each_product(RowStage<NW, U>& st, int as, int ae, const int* __restrict__ JA,
-                                                 const float* __restrict__ VA, const int* __restrict__ IB,
-                                                 const int* __restrict__ JB, const float* __restrict__ VB, F&& f, PreA pre) {
-  unsigned long long t0 = 0, acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
-  for_each_product<NW, U, NEED_VAL>(st, as, ae, JA, VA, IB, JB, VB, f, pre, t0, acc);
-}
-#endif
 
 // dynamic row scheduling for block-per-row kernels: rows of a bin differ by up to 8x in work, a static
 // round-robin leaves the CUs with the light rows idle.  One agent-scope atomic per row (guide: "dequeue",
@@ -974,15 +1094,20 @@ __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ 
                                                          const int* __restrict__ rowFlops, int* __restrict__ IC,
                                                          int* __restrict__ err, int* __restrict__ qctr) {
   __shared__ __attribute__((aligned(16))) int keys[TBL];
-  __shared__ RowStage<NW, U> st;
+  __shared__ typename WalkSel<NW>::type st;
   __shared__ int cnt_s;
   __shared__ int qslot;
   const int tid = threadIdx.x, lane = lane_id();
-  const int first = binPtr[bin], count = binPtr[bin + 1] - first;
-  const int* rows = rowIds + first;
+  if (tid < WAVE) st.dummy[tid] = DUMMY_SLOT;    // (ordered before the first insert by the barrier / wave order below)
+  int first = binPtr[bin], count = binPtr[bin + 1] - first;
   constexpr int QB = NW >= 8 ? 2 : 4;            // rows per dequeue
-  const int stride = (int)gridDim.x;
-  int q = NW > 1 ? next_row<QB>(qctr, &qslot, -1) : (int)blockIdx.x;
+  int stride = (int)gridDim.x;
+  if (NW == 1) {                                 // static schedule: XCD-contiguous (see xcd_range)
+    const XcdRange xr = xcd_range(count);
+    first += xr.lo; count = xr.hi - xr.lo; stride = xr.nb;
+  }
+  const int* rows = rowIds + first;
+  int q = NW > 1 ? next_row<QB>(qctr, &qslot, -1) : (int)(blockIdx.x >> 3);
   RowMeta cur = load_meta_sym(rows, q, count, IA, rowFlops);
   // NW == 1: two rows of metadata and one row of A entries are in flight ahead of the row being processed
   RowMeta nxt = NW == 1 ? load_meta_sym(rows, q + stride, count, IA, rowFlops) : RowMeta{0, 0, 0, 0, 0};
@@ -1006,9 +1131,9 @@ __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ 
     __syncthreads();
     int mine = 0;
     for_each_product<NW, U, false>(st, cur.as, cur.ae, JA, nullptr, IB, JB, nullptr,
-                                   [&](const bool (&act)[U], const int (&col)[U], const float (&val)[U]) {
-      mine += hash_insert_multi<U>(keys, size, shift, act, col, reinterpret_cast<int*>(&st.dummy[threadIdx.x]), err);
-    }, pc);
+                                   [&](const auto& act, const auto& col, const auto& val) {
+      mine += hash_insert_multi(keys, size, shift, act, col, reinterpret_cast<int*>(&st.dummy[lane_id()]), err);
+    }, pc, err);
     const int ws = __builtin_amdgcn_readfirstlane(mine);   // hash_insert_multi counts per wave
     if (NW == 1) {
       if (lane == 0) IC[cur.row] = ws;
@@ -1035,22 +1160,25 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
                                                          float* __restrict__ C, int* __restrict__ err,
                                                          int* __restrict__ qctr) {
   __shared__ __attribute__((aligned(16))) slot_t tab[TBL];   // (column, value) pairs
-  __shared__ RowStage<NW, U> st;
+  __shared__ typename WalkSel<NW>::type st;
   __shared__ int qslot;
   __shared__ int emitted;                        // output positions handed out so far in this row (NW > 1)
   const int tid = threadIdx.x;
+  if (tid < WAVE) st.dummy[tid] = DUMMY_SLOT;
   constexpr int T = WAVE * NW;
-  const int first = binPtr[bin], count = binPtr[bin + 1] - first;
-  const int* rows = rowIds + first;
+  int first = binPtr[bin], count = binPtr[bin + 1] - first;
   constexpr int QB = NW >= 8 ? 2 : 4;            // rows per dequeue
-  const int stride = (int)gridDim.x;
-  int q = NW > 1 ? next_row<QB>(qctr, &qslot, -1) : (int)blockIdx.x;
+  int stride = (int)gridDim.x;
+  if (NW == 1) {                                 // static schedule: XCD-contiguous (see xcd_range)
+    const XcdRange xr = xcd_range(count);
+    first += xr.lo; count = xr.hi - xr.lo; stride = xr.nb;
+  }
+  const int* rows = rowIds + first;
+  int q = NW > 1 ? next_row<QB>(qctr, &qslot, -1) : (int)(blockIdx.x >> 3);
   RowMeta cur = load_meta_num(rows, q, count, IA, IC);
   RowMeta nxt = NW == 1 ? load_meta_num(rows, q + stride, count, IA, IC) : RowMeta{0, 0, 0, 0, 0};
   PreA pc = NW == 1 ? load_pre(cur, JA, VA, true) : PreA{0, 0.f, false};
-  STAMP_DECL;
   while (q < count) {
-    STAMP(0);
     int qn;
     PreA pn{0, 0.f, false};
     RowMeta nn{0, 0, 0, 0, 0};
@@ -1062,7 +1190,6 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
       qn = next_row<QB>(qctr, &qslot, q);
       nxt = load_meta_num(rows, qn, count, IA, IC);
     }
-    STAMP(1);
     const int off = cur.x0;
     const int want = cur.x1 - off;                      // exact distinct count from the symbolic pass
     const int size = next_pow2_clamped(2 * want, T > 64 ? T : 64, TBL);
@@ -1070,19 +1197,23 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
     clear_slots(tab, size, tid, T);
     if (NW > 1 && tid == 0) emitted = 0;
     __syncthreads();
-    STAMP(2);
+    if (!ABL(8))
     for_each_product<NW, U, true>(st, cur.as, cur.ae, JA, VA, IB, JB, VB,
-                                  [&](const bool (&act)[U], const int (&col)[U], const float (&val)[U]) {
-      hash_accum_multi<U>(tab, size, shift, act, col, val, &st.dummy[threadIdx.x], err);
-    }, pc STAMP_ARGS);
-    STAMP(3);
+                                  [&](const auto& act, const auto& col, const auto& val) {
+      if (ABL(1)) {
+#pragma unroll
+        for (int u = 0; u < (int)(sizeof(col) / sizeof(col[0])); ++u) asm volatile("" :: "v"(col[u]), "v"(val[u]));
+      } else
+      hash_accum_multi(tab, size, shift, act, col, val, &st.dummy[lane_id()], err);
+    }, pc, err);
     // compaction: wave w sweeps the contiguous slots [w*per, w*per+per) 64 at a time, so that a wave's stores
     // land on consecutive output positions.  One wave: a single pass.  Several waves: a wave reads its slots into
     // registers, claims its share of the row's output range with ONE LDS atomic (any order inside a row is a valid
     // CSR row) and emits from the registers: no counting sweep, no block scan, no barrier.
     const int per = size / NW;
     const int lane = lane_id(), w = tid >> 6;
-    if (NW == 1) {
+    if (ABL(4)) { __syncthreads(); }
+    else if (NW == 1) {
       int pos = 0;                                    // relative to the row: small 32-bit offsets for both stores
       int* const JCrow = JC + off;
       float* const Crow = C + off;
@@ -1101,12 +1232,10 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
       __syncthreads();
       if (tid == 0 && emitted != want) atomicOr(err, ERRF_COUNT_MISMATCH);
     }
-    STAMP(4);
     cur = nxt;
     if (NW == 1) { nxt = nn; pc = pn; }
     q = qn;
   }
-  STAMP_FLUSH(NW == 1 ? 1 : NW == 4 ? 2 : 3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1127,17 +1256,17 @@ constexpr int SYM_WORDS = SYM_WC / 32;
 constexpr int BIG_WC = 262144;                 // columns covered by the rank kernel (32 KB bitmap)
 constexpr int BIG_WORDS = BIG_WC / 32;         // 8192
 constexpr int BIG_WPT = BIG_WORDS / BIG_THREADS;  // 8 words per thread
-constexpr int BIG_CAP = 18432;                 // float accumulators per rank pass (72 KB)
-constexpr int BH_SLOTS = 17408;                // hash kernel: 136 KB of (key, value) pairs (17 x 1024 slots, not a power of two)
-constexpr int BH_CAP = 10240;                  // distinct columns per hash pass (load <= 0.6 incl. partition skew; measured
+constexpr int BIG_CAP = 16384;                 // float accumulators per rank pass (64 KB)
+constexpr int BH_SLOTS = 16384;                // hash kernel: 128 KB of (key, value) pairs (what the walk stage leaves of 160 KB)
+constexpr int BH_CAP = 11264;                  // distinct columns per hash pass (load <= 0.6 incl. partition skew; measured
                                                // best of 8704/10240/12800 once later passes stream parked products)
-constexpr int BH_CAP_MAX = 12800;              // SPGEMM_BHCAP may raise the cap to this (load 0.74)
+constexpr int BH_CAP_MAX = 12288;              // SPGEMM_BHCAP may raise the cap to this (load 0.74)
 constexpr int BH_SPILL = 1 << 18;              // (col,val) pairs a multi-pass row may park in HBM per block (2 MB)
 constexpr int BH_MAXCLS = 32;                  // hash classes (passes) with their own parking region
 
 struct BigSymShared {
   unsigned bitmap[SYM_WORDS];
-  RowStage<BIG_NW, BIG_U> st;
+  WalkStageN<BIG_NW> st;
   int red[BIG_NW];
 };
 constexpr int BIG_GROUPS = BIG_WORDS / WAVE;   // 128 groups of 64 bitmap words
@@ -1146,7 +1275,7 @@ struct BigNumShared {
   unsigned bitmap[BIG_WORDS];
   int prefix[BIG_WORDS];
   float acc[BIG_CAP];
-  RowStage<BIG_NW, BIG_U> st;
+  WalkStageN<BIG_NW> st;
   int red[BIG_NW];
   int gtot[BIG_GROUPS];
   int gbase[BIG_GROUPS];
@@ -1154,7 +1283,7 @@ struct BigNumShared {
 };
 struct BigHashShared {
   slot_t tab[BH_SLOTS];          // (column, value) pairs
-  RowStage<BIG_NW, BH_U> st;
+  WalkStageN<BIG_NW> st;
   int red[BIG_NW];
   int spillCnt[BH_MAXCLS];
   int emitted;
@@ -1200,7 +1329,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sym_big(const int* __restrict__
         for (int u = 0; u < BIG_U; ++u) {            // predicated by value: OR-ing 0 changes nothing
           const int c = col[u] - w0;
           const bool ok = act[u] && (unsigned)c < (unsigned)wc;
-          atomicOr(ok ? &sh.bitmap[c >> 5] : reinterpret_cast<unsigned*>(&sh.st.dummy[threadIdx.x]), ok ? 1u << (c & 31) : 0u);
+          atomicOr(ok ? &sh.bitmap[c >> 5] : reinterpret_cast<unsigned*>(&sh.st.dummy[lane_id()]), ok ? 1u << (c & 31) : 0u);
         }
       });
       int mine = 0;
@@ -1234,9 +1363,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
   BigNumShared& sh = *reinterpret_cast<BigNumShared*>(smem_raw);
   const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
-  STAMP_DECL;
   for (int q = next_row(qctr, &sh.red[0]); q < count; q = next_row(qctr, &sh.red[0])) {
-    STAMP(0);
     const int row = rowIds[first + q];
     const int as = IA[row], ae = IA[row + 1];
     const int outBase = IC[row];
@@ -1258,7 +1385,6 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
         }
       });
     }
-    STAMP(1);
     // exclusive popcount prefix over the words.  Wave w owns the 64-word groups w, w+16, ...: consecutive lanes
     // read consecutive words (no bank conflicts) and a dense column range is shared by all waves.
     int lexcl[BIG_GPW];
@@ -1291,7 +1417,6 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
     // BIG_CAP ranks at a time: column indices first (already sorted; scattered into LDS by rank, then stored
     // coalesced), then the values accumulated by rank
     int* accI = reinterpret_cast<int*>(sh.acc);
-    STAMP(2);
     for (int lo = 0; lo < cntw; lo += BIG_CAP) {
       const int span = min(BIG_CAP, cntw - lo);
 #pragma unroll
@@ -1307,15 +1432,11 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
           ++pos;
         }
       }
-      STAMP(11);
       __syncthreads();
-      STAMP(7);
       for (int i = tid; i < span; i += BIG_THREADS) JC[outBase + lo + i] = accI[i];
       __syncthreads();
-      STAMP(3);
       for (int i = tid; i < span; i += BIG_THREADS) sh.acc[i] = 0.f;
       __syncthreads();
-      STAMP(4);
       for_each_product<BIG_NW, BIG_U, true>(sh.st, as, ae, JA, VA, IB, JB, VB,
                                             [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&val)[BIG_U]) {
         int rk[BIG_U];
@@ -1329,17 +1450,13 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
 #pragma unroll
         for (int u = 0; u < BIG_U; ++u)
           ok[u] = act[u] && (unsigned)col[u] < (unsigned)n && (unsigned)rk[u] < (unsigned)span;
-        lds_fadd_multi<BIG_U>(sh.acc, rk, ok, val, reinterpret_cast<int*>(&sh.st.dummy[threadIdx.x]));
-      } STAMP_ARGS);
-      STAMP(5);
+        lds_fadd_multi(sh.acc, rk, ok, val, reinterpret_cast<int*>(&sh.st.dummy[lane_id()]));
+      });
       for (int i = tid; i < span; i += BIG_THREADS) C[outBase + lo + i] = sh.acc[i];
       __syncthreads();
-      STAMP(6);
     }
     __syncthreads();
   }
-  STAMP(7);
-  STAMP_FLUSH(0);
 }
 
 // numeric B (any n): multi-pass LDS hash.  A row with more distinct columns than one table holds takes npass passes,
@@ -1365,9 +1482,8 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
   const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
   int2* const park = spill ? spill + (size_t)blockIdx.x * (size_t)spillCap : nullptr;
-  STAMP_DECL;
+  if (tid < WAVE) sh.st.dummy[tid] = DUMMY_SLOT;
   for (int q = next_row(qctr, &sh.red[0]); q < count; q = next_row(qctr, &sh.red[0])) {
-    STAMP(0);
     const int row = rowIds[first + q];
     const int as = IA[row], ae = IA[row + 1];
     const int outBase = IC[row];
@@ -1392,7 +1508,6 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
       if (pass == 0 && tid < BH_MAXCLS) sh.spillCnt[tid] = 0;
       if (pass == 0 && tid == 0) { sh.emitted = 0; sh.ovf = 0; }
       __syncthreads();
-      STAMP(1);
       if (pass == 0 || !useSpill) {
         for_each_product<BIG_NW, BH_U, true>(sh.st, as, ae, JA, VA, IB, JB, VB,
                                               [&](const bool (&act)[BH_U], const int (&col)[BH_U], const float (&val)[BH_U]) {
@@ -1403,7 +1518,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
             cls[u] = npass == 1 ? 0u : bh_class(col[u], npass);
             mine[u] = act[u] && cls[u] == pass;
           }
-          hash_accum_multi<BH_U, false>(sh.tab, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
+          hash_accum_multi<false>(sh.tab, size, shift, mine, col, val, &sh.st.dummy[lane_id()], err);
           if (useSpill) {                              // block-uniform; here pass == 0
             for (unsigned c = 1; c < npass; ++c) {
               unsigned long long mk[BH_U];
@@ -1427,8 +1542,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
               }
             }
           }
-        } STAMP_ARGS);
-        STAMP(2);
+        });
         if (pass == 0 && useSpill && sh.ovf) {        // block-uniform (read after the walk's closing barrier)
           __syncthreads();                             // everyone has seen the flag before it is reset
           useSpill = false;
@@ -1456,23 +1570,19 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
             const int idx = i0 + BIG_THREADS * BH_U + u * BIG_THREADS + tid;
             nxt[u] = src[idx < cnt ? idx : 0];
           }
-          hash_accum_multi<BH_U, false>(sh.tab, size, shift, mine, col, val, &sh.st.dummy[threadIdx.x], err);
+          hash_accum_multi<false>(sh.tab, size, shift, mine, col, val, &sh.st.dummy[lane_id()], err);
         }
         __syncthreads();
-        STAMP(3);
       }
       // compaction: wave w emits the slots [w*per, w*per+per); its share of the row's output range comes from one
       // LDS atomic (the counter runs on across the passes of a row)
       emit_claimed<BH_SLOTS / BIG_NW / WAVE>(sh.tab, w * per, per, &sh.emitted, outBase, outEnd, JC, C);
       __syncthreads();
-      STAMP(4);
       ++pass;
     }
     if (tid == 0 && sh.emitted != want) atomicOr(err, ERRF_COUNT_MISMATCH);
     __syncthreads();
   }
-  STAMP(0);
-  STAMP_FLUSH(0);
 }
 
 // ------------------------------------------------------------------------------------------------

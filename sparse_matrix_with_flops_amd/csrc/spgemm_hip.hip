@@ -220,6 +220,9 @@ extern "C" int spgemm_hip_create(spgemm_handle** out, int device) {
   for (auto& e : h->kev) HIPCHK(hipEventCreate(&e));
   for (auto& u : h->kused) u = false;
   { const char* e = getenv("SPGEMM_CONCURRENT"); h->serial = !(e && e[0] == '1'); }
+#ifdef SMF_ABLATE
+  { const char* e = getenv("SPGEMM_ABLATE"); int v = e ? atoi(e) : 0; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(smf::g_ablate), &v, sizeof(int))); }
+#endif
   { const char* e = getenv("SPGEMM_H1SYM"); if (e) { const int c = atoi(e); if (c >= 1 && c <= 32) h->h1sym = c; } }
   { const char* e = getenv("SPGEMM_BHMARGIN"); if (e) { const int c = atoi(e); if (c >= 10 && c <= 400) h->bhMargin = c; } }
   { const char* e = getenv("SPGEMM_BHCAP"); if (e) { const int c = atoi(e); if (c >= 1024 && c <= BH_CAP_MAX) h->bhCap = c; } }
@@ -309,6 +312,8 @@ extern "C" int spgemm_hip_memcpy_d2d(void* dst, const void* src, size_t bytes) {
 // ------------------------------------------------------------------------------------------------
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline int clampi(long long v, int lo, int hi) { return (int)std::max<long long>(lo, std::min<long long>(v, hi)); }
+// grid of a statically scheduled kernel: a multiple of 8 (one contiguous eighth of the work per XCD: xcd_range)
+static inline int grid8(long long want, int hi) { return (clampi(want, 8, hi) + 7) & ~7; }
 
 static const char* kKernelNames[SPGEMM_NKERNELS] = {
     "k_row_flops", "k_bin_scan", "k_scatter_rows", "k_sym_small<4,32>", "k_sym_g16", "k_sym_hash<1,1024>",
@@ -395,15 +400,15 @@ static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJA, con
              dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 2); }
   { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_SYM_HASH1, st);
     const int* sb = h->dsmall->slotBase;         // bin 5 = two layout slots: table 512 up to 256 products, 1024 above
-    LAUNCH_U(k_sym_hash, 1, 512, dim3(clampi(m, 1, cu * h->h1sym)), dim3(64), st, sb, SLOT_H1A, rowIds, dIA,
+    LAUNCH_U(k_sym_hash, 1, 512, dim3(grid8(m, cu * h->h1sym)), dim3(64), st, sb, SLOT_H1A, rowIds, dIA,
              dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 3);
-    LAUNCH_U(k_sym_hash, 1, 1024, dim3(clampi(m, 1, cu * h->h1sym)), dim3(64), st, sb, SLOT_H1B, rowIds, dIA,
+    LAUNCH_U(k_sym_hash, 1, 1024, dim3(grid8(m, cu * h->h1sym)), dim3(64), st, sb, SLOT_H1B, rowIds, dIA,
              dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 3); }
   { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_SYM_G16, st);
-    hipLaunchKernelGGL((k_sym_g16<128, 4>), dim3(clampi(cdiv(m, 16), 1, cu * 16)), dim3(256), 0, st, bp, 4,
+    hipLaunchKernelGGL((k_sym_g16<128, 4>), dim3(grid8(cdiv(m, 16), cu * 16)), dim3(256), 0, st, bp, 4,
                        rowIds, dIA, dJA, dIB, dJB, h->rowFlops, dIC, err); }
   { KTimer t(h, SPGEMM_K_SYM_SMALL4);
-    hipLaunchKernelGGL((k_sym_small<4, 32>), dim3(clampi(cdiv(m, 64), 1, cu * 8)), dim3(256), 0, h->stream, bp, 2, 4,
+    hipLaunchKernelGGL((k_sym_small<4, 32>), dim3(grid8(cdiv(m, 64), cu * 8)), dim3(256), 0, h->stream, bp, 2, 4,
                        rowIds, dIA, dJA, dIB, dJB, h->rowFlops, dIC, err); }
   join_streams(h);
   HIPCHK(hipGetLastError());
@@ -459,15 +464,15 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const int* dJA, cons
     const int* sb = h->dsmall->slotBase;
     const int* hs_ = h->mirror.slotBase;
     const int na = hs_[SLOT_H1A + 1] - hs_[SLOT_H1A], nb = hs_[SLOT_H1B + 1] - hs_[SLOT_H1B];
-    if (na > 0) LAUNCH_U(k_num_hash, 1, 512, dim3(clampi(na, 1, cu * 24)), dim3(64), st, sb, SLOT_H1A,
+    if (na > 0) LAUNCH_U(k_num_hash, 1, 512, dim3(grid8(na, cu * 24)), dim3(64), st, sb, SLOT_H1A,
                          rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 7);
-    if (nb > 0) LAUNCH_U(k_num_hash, 1, 1024, dim3(clampi(nb, 1, cu * 16)), dim3(64), st, sb, SLOT_H1B,
+    if (nb > 0) LAUNCH_U(k_num_hash, 1, 1024, dim3(grid8(nb, cu * 16)), dim3(64), st, sb, SLOT_H1B,
                          rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 7); }
   if (rows(4, 5) > 0) { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_NUM_G16, st);
-    hipLaunchKernelGGL((k_num_g16<128, 4>), dim3(clampi(cdiv(rows(4, 5), 16), 1, cu * 16)), dim3(256), 0, st,
+    hipLaunchKernelGGL((k_num_g16<128, 4>), dim3(grid8(cdiv(rows(4, 5), 16), cu * 16)), dim3(256), 0, st,
                        bp, 4, rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err); }
   if (rows(1, 4) > 0) { KTimer t(h, SPGEMM_K_NUM_SMALL4);
-    hipLaunchKernelGGL((k_num_small<4, 32>), dim3(clampi(cdiv(rows(1, 4), 64), 1, cu * 8)), dim3(256), 0, h->stream, bp,
+    hipLaunchKernelGGL((k_num_small<4, 32>), dim3(grid8(cdiv(rows(1, 4), 64), cu * 8)), dim3(256), 0, h->stream, bp,
                        1, 4, rowIds, dIA, dJA, dA, dIB, dJB, dB, h->rowFlops, dIC, dJC, dC, err); }
   join_streams(h);
   HIPCHK(hipGetLastError());
@@ -543,7 +548,9 @@ static int numeric_phase(spgemm_handle* h, const int* dIA, const int* dJA, const
       hipStreamSynchronize(s) != hipSuccess)
     return fail(SPGEMM_ERR_HIP, "numeric phase failed: %s", hipGetErrorString(hipGetLastError()));
   h->sym_m = -1;
+#ifndef SMF_ABLATE
   if (h->hsmall->err) return fail(SPGEMM_ERR_INTERNAL, "device invariant broken in numeric phase (flags=%d)", h->hsmall->err);
+#endif
   spgemm_stats& st = h->stats;
   hipEventElapsedTime(&st.ms_numeric, h->ev[4], h->ev[5]);
   st.ms_total += st.ms_numeric;
@@ -960,15 +967,6 @@ extern "C" int spgemm_hip_selftest(spgemm_handle* h) {
   return SPGEMM_OK;
 }
 
-#ifdef SMF_STAMPS
-// diagnostic build only: read and clear the per-phase cycle sums
-extern "C" int spgemm_hip_debug_stamps(unsigned long long* out /*[4][16]*/, int clear) {
-  HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(smf::g_stamps), sizeof(unsigned long long) * 64));
-  if (clear) { unsigned long long z[64] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(smf::g_stamps), z, sizeof(z))); }
-  return SPGEMM_OK;
-}
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // COO -> CSR on the device (the step in front of the path)

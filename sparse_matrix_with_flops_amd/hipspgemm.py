@@ -19,7 +19,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspgemm_hip.so")
+# SPGEMM_LIB: diagnostic builds only (make -C csrc ablate); the product library is the default
+LIB_PATH = os.environ.get("SPGEMM_LIB") or os.path.join(_HERE, "libspgemm_hip.so")
 
 NBINS = 9
 HV_LEN = 9

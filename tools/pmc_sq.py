@@ -12,6 +12,8 @@ for k in sorted(tot):
     c = {x: tot[k][x] / max(len(n[k][x]), 1) for x in tot[k]}
     if c.get("SQ_WAVE_CYCLES", 0) < 1e7: continue
     g = lambda x: c.get(x, float("nan"))
-    print(f"{k:26s} wait_any/wave_cyc={g('SQ_WAIT_ANY')/g('SQ_WAVE_CYCLES'):.2f}  inst_valu={g('SQ_INSTS_VALU'):.3g} salu={g('SQ_INSTS_SALU'):.3g} lds={g('SQ_INSTS_LDS'):.3g} vmem_rd={g('SQ_INSTS_VMEM_RD'):.3g}"
-          f"  busy_cyc={g('SQ_BUSY_CYCLES'):.3g} active_valu={g('SQ_ACTIVE_INST_VALU'):.3g} active_lds={g('SQ_ACTIVE_INST_LDS'):.3g} active_vmem={g('SQ_ACTIVE_INST_VMEM'):.3g} active_sca={g('SQ_ACTIVE_INST_SCA'):.3g}"
-          f"  wait_inst_lds={g('SQ_WAIT_INST_LDS'):.3g} lds_bank_conflict={g('SQ_LDS_BANK_CONFLICT'):.3g} lds_idx_active={g('SQ_LDS_IDX_ACTIVE'):.3g} busy_cu={g('SQ_BUSY_CU_CYCLES'):.3g}")
+    wc = g('SQ_WAVE_CYCLES')
+    print(f"{k:26s} wave_cyc={wc:.3g} wait_any={g('SQ_WAIT_ANY')/wc:.2f} wait_inst_any={g('SQ_WAIT_INST_ANY')/wc:.2f} active_inst_any={g('SQ_ACTIVE_INST_ANY')/wc:.2f}"
+          f" busy_cyc={g('SQ_BUSY_CYCLES'):.3g} waves={g('SQ_WAVES'):.3g} | insts valu={g('SQ_INSTS_VALU'):.3g} salu={g('SQ_INSTS_SALU'):.3g} lds={g('SQ_INSTS_LDS'):.3g} vmem_rd={g('SQ_INSTS_VMEM_RD'):.3g} vmem_wr={g('SQ_INSTS_VMEM_WR'):.3g} smem={g('SQ_INSTS_SMEM'):.3g}"
+          f" | active valu={g('SQ_ACTIVE_INST_VALU'):.3g} lds={g('SQ_ACTIVE_INST_LDS'):.3g} vmem={g('SQ_ACTIVE_INST_VMEM'):.3g} sca={g('SQ_ACTIVE_INST_SCA'):.3g}"
+          f" | wait_inst_lds={g('SQ_WAIT_INST_LDS'):.3g} bank_conflict={g('SQ_LDS_BANK_CONFLICT'):.3g} lds_idx_active={g('SQ_LDS_IDX_ACTIVE'):.3g} busy_cu={g('SQ_BUSY_CU_CYCLES'):.3g} thread_cyc_valu={g('SQ_THREAD_CYCLES_VALU'):.3g}")
