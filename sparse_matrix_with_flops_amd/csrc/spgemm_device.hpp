@@ -377,8 +377,22 @@ __device__ __forceinline__ void emit_claimed(const slot_t* tab, int base, int pe
 constexpr int K1_THREADS = 256;
 constexpr int FL_SHORT = 8;
 
+// K1a: per A entry, where its B row starts and how long it is -- ONE coalesced record per entry.  Every later kernel
+// stages a row from these records instead of walking the dependent chain JA -> IB (two memory round trips per row in
+// every symbolic and numeric kernel, and three random IB gathers per entry over the whole pipeline instead of one).
+__global__ __launch_bounds__(256) void k_entry_lens(int nnzA, const int* __restrict__ JA, const int* __restrict__ IB,
+                                                     int2* __restrict__ SBL) {
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < nnzA; p += gridDim.x * 256) {
+    const int j = JA[p];
+    const int2 be = make_int2(IB[j], IB[j + 1]);
+    SBL[p] = make_int2(be.x, max(be.y - be.x, 0));
+  }
+}
+
+// SBL != nullptr: lengths come from K1a's records (coalesced); otherwise gathered through JA -> IB
 __global__ __launch_bounds__(K1_THREADS) void k_row_flops(
     int m, const int* __restrict__ IA, const int* __restrict__ JA, const int* __restrict__ IB,
+    const int2* __restrict__ SBL,
     int* __restrict__ rowFlops, unsigned char* __restrict__ binId, int* __restrict__ blockHist,
     unsigned long long* __restrict__ blockP, int* __restrict__ IC) {
   __shared__ int hist[NSLOTS];
@@ -391,7 +405,10 @@ __global__ __launch_bounds__(K1_THREADS) void k_row_flops(
   int rs = 0, re = 0;
   if (r < m) { rs = IA[r]; re = IA[r + 1]; }
   unsigned long long f = 0;
-  {
+  if (SBL) {
+#pragma unroll
+    for (int t = 0; t < FL_SHORT; ++t) f += rs + t < re ? (unsigned)SBL[rs + t].y : 0u;
+  } else {
     int js[FL_SHORT];                                 // all JA loads first, then all IB loads: two round trips
 #pragma unroll
     for (int t = 0; t < FL_SHORT; ++t) js[t] = rs + t < re ? JA[rs + t] : -1;
@@ -405,7 +422,8 @@ __global__ __launch_bounds__(K1_THREADS) void k_row_flops(
     longMask &= longMask - 1;
     const int s = __shfl(rs, src, 64) + FL_SHORT, e = __shfl(re, src, 64);
     unsigned long long part = 0;
-    for (int p = s + lane; p < e; p += WAVE) { const int j = JA[p]; part += (unsigned)(IB[j + 1] - IB[j]); }
+    if (SBL) { for (int p = s + lane; p < e; p += WAVE) part += (unsigned)SBL[p].y; }
+    else { for (int p = s + lane; p < e; p += WAVE) { const int j = JA[p]; part += (unsigned)(IB[j + 1] - IB[j]); } }
     part = wave_sum_u64(part);
     if (lane == src) f += part;
   }
@@ -531,8 +549,8 @@ __device__ __forceinline__ XcdRange xcd_range(int count) {
 template <int G, int TBL>
 __global__ __launch_bounds__(256) void k_sym_small(const int* __restrict__ binPtr, int binLo, int binHi,
                                                     const int* __restrict__ rowIds,
-                                                    const int* __restrict__ IA, const int* __restrict__ JA,
-                                                    const int* __restrict__ IB, const int* __restrict__ JB,
+                                                    const int* __restrict__ IA, const int2* __restrict__ SBL,
+                                                    const int* __restrict__ JB,
                                                     const int* __restrict__ rowFlops, int* __restrict__ IC,
                                                     int* __restrict__ err) {
   constexpr int GROUPS = 256 / G;
@@ -556,8 +574,8 @@ __global__ __launch_bounds__(256) void k_sym_small(const int* __restrict__ binPt
     if (live) {
       const int as = IA[row], ae = IA[row + 1];
       for (int ap = as; ap < ae; ++ap) {
-        const int j = JA[ap];
-        const int bs = IB[j], be = IB[j + 1];
+        const int2 sbl = SBL[ap];
+        const int bs = sbl.x, be = sbl.x + sbl.y;
         for (int bp = bs + gl; bp < be; bp += G) {
           bool isnew;
           hash_insert(keys[g], size, shift, JB[bp], &isnew, err);
@@ -576,9 +594,9 @@ __global__ __launch_bounds__(256) void k_sym_small(const int* __restrict__ binPt
 template <int G, int TBL>
 __global__ __launch_bounds__(256) void k_num_small(const int* __restrict__ binPtr, int binLo, int binHi,
                                                     const int* __restrict__ rowIds,
-                                                    const int* __restrict__ IA, const int* __restrict__ JA,
+                                                    const int* __restrict__ IA, const int2* __restrict__ SBL,
                                                     const float* __restrict__ VA,
-                                                    const int* __restrict__ IB, const int* __restrict__ JB,
+                                                    const int* __restrict__ JB,
                                                     const float* __restrict__ VB,
                                                     const int* __restrict__ rowFlops,
                                                     const int* __restrict__ IC, int* __restrict__ JC,
@@ -603,9 +621,9 @@ __global__ __launch_bounds__(256) void k_num_small(const int* __restrict__ binPt
     if (live) {
       const int as = IA[row], ae = IA[row + 1];
       for (int ap = as; ap < ae; ++ap) {
-        const int j = JA[ap];
+        const int2 sbl = SBL[ap];
         const float a = VA[ap];
-        const int bs = IB[j], be = IB[j + 1];
+        const int bs = sbl.x, be = sbl.x + sbl.y;
         for (int bp = bs + gl; bp < be; bp += G) hash_accum(tab[g], size, shift, JB[bp], a * VB[bp], err);
       }
     }
@@ -646,17 +664,17 @@ __device__ __forceinline__ int row16_incl_add(int v) {   // inclusive scan insid
 struct G16Stage { int incl[16]; int off[16]; float aval[16]; };
 
 template <int U, bool NEED_VAL, class F>
-__device__ __forceinline__ void g16_walk(G16Stage& st, int gl, int as, int ae, const int* __restrict__ JA,
-                                         const float* __restrict__ VA, const int* __restrict__ IB,
+__device__ __forceinline__ void g16_walk(G16Stage& st, int gl, int as, int ae, const int2* __restrict__ SBL,
+                                         const float* __restrict__ VA,
                                          const int* __restrict__ JB, const float* __restrict__ VB, F&& f) {
   for (int chunk = as; chunk < ae; chunk += 16) {
     const int ap = chunk + gl;
     int len = 0, bs = 0;
     float a = 0.f;
     if (ap < ae) {
-      const int j = JA[ap];
-      bs = IB[j];
-      len = IB[j + 1] - bs;
+      const int2 sbl = SBL[ap];
+      bs = sbl.x;
+      len = sbl.y;
       if (NEED_VAL) a = VA[ap];
     }
     const int incl = row16_incl_add(len);
@@ -701,8 +719,8 @@ __device__ __forceinline__ void g16_walk(G16Stage& st, int gl, int as, int ae, c
 template <int TBL, int U>
 __global__ __launch_bounds__(256) void k_sym_g16(const int* __restrict__ binPtr, int bin,
                                                   const int* __restrict__ rowIds,
-                                                  const int* __restrict__ IA, const int* __restrict__ JA,
-                                                  const int* __restrict__ IB, const int* __restrict__ JB,
+                                                  const int* __restrict__ IA, const int2* __restrict__ SBL,
+                                                  const int* __restrict__ JB,
                                                   const int* __restrict__ rowFlops, int* __restrict__ IC,
                                                   int* __restrict__ err) {
   __shared__ int keys[16][TBL];
@@ -724,7 +742,7 @@ __global__ __launch_bounds__(256) void k_sym_g16(const int* __restrict__ binPtr,
     wave_lds_sync();
     int mine = 0;
     if (live) {
-      g16_walk<U, false>(st[g], gl, IA[row], IA[row + 1], JA, nullptr, IB, JB, nullptr, [&](bool active, int col, float) {
+      g16_walk<U, false>(st[g], gl, IA[row], IA[row + 1], SBL, nullptr, JB, nullptr, [&](bool active, int col, float) {
         if (active) {
           bool isnew;
           hash_insert(keys[g], size, shift, col, &isnew, err);
@@ -741,9 +759,9 @@ __global__ __launch_bounds__(256) void k_sym_g16(const int* __restrict__ binPtr,
 template <int TBL, int U>
 __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr, int bin,
                                                   const int* __restrict__ rowIds,
-                                                  const int* __restrict__ IA, const int* __restrict__ JA,
+                                                  const int* __restrict__ IA, const int2* __restrict__ SBL,
                                                   const float* __restrict__ VA,
-                                                  const int* __restrict__ IB, const int* __restrict__ JB,
+                                                  const int* __restrict__ JB,
                                                   const float* __restrict__ VB,
                                                   const int* __restrict__ IC, int* __restrict__ JC,
                                                   float* __restrict__ C, int* __restrict__ err) {
@@ -766,7 +784,7 @@ __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr,
     for (int i = gl; i < size; i += 16) tab[g][i] = EMPTY_SLOT;
     wave_lds_sync();
     if (live) {
-      g16_walk<U, true>(st[g], gl, IA[row], IA[row + 1], JA, VA, IB, JB, VB, [&](bool active, int col, float v) {
+      g16_walk<U, true>(st[g], gl, IA[row], IA[row + 1], SBL, VA, JB, VB, [&](bool active, int col, float v) {
         if (active) hash_accum(tab[g], size, shift, col, v, err);
       });
     }
@@ -805,7 +823,7 @@ __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr,
 constexpr int LONG_LEN = WAVE;           // B rows of at least this length are walked by whole waves
 
 // first chunk of A entries fetched ahead of time (wave-per-row kernels prefetch the next row's while they work)
-struct PreA { int j; float a; bool valid; };
+struct PreA { int bs, len; float a; bool valid; };
 
 struct WalkStage1 {                      // one wave per row
   unsigned long long marks[WAVE];        // ownership marks of the staged group (64 entries x <= 63 products)
@@ -835,16 +853,17 @@ struct GroupLanes {                      // what the staging wave keeps in regis
 
 template <bool NEED_VAL, int RS, int LONGLEN>
 __device__ __forceinline__ GroupLanes stage_group(unsigned long long* marks, char* rec, int ap, int ae,
-                                                  const int* __restrict__ JA, const float* __restrict__ VA,
-                                                  const int* __restrict__ IB, PreA pre) {
+                                                  const int2* __restrict__ SBL, const float* __restrict__ VA, PreA pre) {
   const int lane = lane_id();
   GroupLanes g;
   g.bs = 0; g.len = 0; g.a = 0.f;
   if (ap < ae) {
-    const int j = pre.valid ? pre.j : JA[ap];
-    g.bs = IB[j];
-    g.len = max(IB[j + 1] - g.bs, 0);
-    if (NEED_VAL) g.a = pre.valid ? pre.a : VA[ap];
+    if (pre.valid) { g.bs = pre.bs; g.len = pre.len; g.a = pre.a; }
+    else {
+      const int2 sbl = SBL[ap];
+      g.bs = sbl.x; g.len = sbl.y;
+      if (NEED_VAL) g.a = VA[ap];
+    }
   }
   const bool isLong = g.len >= LONGLEN;
   const int slen = isLong ? 0 : g.len;
@@ -941,13 +960,13 @@ __device__ __forceinline__ void with_rounds(int R, G&& g) {
 // f is a generic callable: f(act[R], col[R], val[R]) for R in {1,2,3,4,6,8}.
 template <int NW, int U, bool NEED_VAL, class F>
 __device__ __forceinline__ typename std::enable_if<NW == 1>::type
-for_each_product(WalkStage1& st, int as, int ae, const int* __restrict__ JA, const float* __restrict__ VA,
-                 const int* __restrict__ IB, const int* __restrict__ JB, const float* __restrict__ VB, F&& f,
-                 PreA pre = PreA{0, 0.f, false}, int* err = nullptr) {
+for_each_product(WalkStage1& st, int as, int ae, const int2* __restrict__ SBL, const float* __restrict__ VA,
+                 const int* __restrict__ JB, const float* __restrict__ VB, F&& f,
+                 PreA pre = PreA{0, 0, 0.f, false}, int* err = nullptr) {
   const int lane = lane_id();
   for (int gb = as; gb < ae; gb += WAVE) {
-    const GroupLanes g = stage_group<NEED_VAL, 8, 0x40000000>(st.marks, reinterpret_cast<char*>(st.rec), gb + lane, ae, JA, VA, IB,
-                                                              gb == as ? pre : PreA{0, 0.f, false});
+    const GroupLanes g = stage_group<NEED_VAL, 8, 0x40000000>(st.marks, reinterpret_cast<char*>(st.rec), gb + lane, ae, SBL, VA,
+                                                              gb == as ? pre : PreA{0, 0, 0.f, false});
     if (g.T > WAVE * WAVE) {                             // cannot happen for rows of this bin (<= 512 products)
       if (err && lane == 0) atomicOr(err, ERRF_TABLE_FULL);
       continue;
@@ -975,9 +994,9 @@ for_each_product(WalkStage1& st, int as, int ae, const int* __restrict__ JA, con
 // ---- NW waves per row
 template <int NW, int U, bool NEED_VAL, class F>
 __device__ __forceinline__ typename std::enable_if<(NW > 1)>::type
-for_each_product(WalkStageN<NW>& st, int as, int ae, const int* __restrict__ JA, const float* __restrict__ VA,
-                 const int* __restrict__ IB, const int* __restrict__ JB, const float* __restrict__ VB, F&& f,
-                 PreA pre = PreA{0, 0.f, false}, int* err = nullptr) {
+for_each_product(WalkStageN<NW>& st, int as, int ae, const int2* __restrict__ SBL, const float* __restrict__ VA,
+                 const int* __restrict__ JB, const float* __restrict__ VB, F&& f,
+                 PreA pre = PreA{0, 0, 0.f, false}, int* err = nullptr) {
   (void)err;
   static_assert(NW <= 16, "the unit table of a chunk lives in the first 16 lanes");
   constexpr int K = WAVE * NW;
@@ -987,8 +1006,8 @@ for_each_product(WalkStageN<NW>& st, int as, int ae, const int* __restrict__ JA,
   for (int chunk = as; chunk < ae; chunk += K) {
     // ---- wave w stages group w of the chunk
     {
-      const GroupLanes g = stage_group<NEED_VAL, 16, LONG_LEN>(st.marks[w], reinterpret_cast<char*>(st.rec[w]), chunk + tid, ae, JA, VA,
-                                                     IB, PreA{0, 0.f, false});
+      const GroupLanes g = stage_group<NEED_VAL, 16, LONG_LEN>(st.marks[w], reinterpret_cast<char*>(st.rec[w]), chunk + tid, ae, SBL, VA,
+                                                     PreA{0, 0, 0.f, false});
       const bool isLong = (g.lmask >> lane) & 1ull;
       const int units = isLong ? (g.len + UP - 1) / UP : 0;
       const int uincl = wave_incl_add(units);
@@ -1075,10 +1094,10 @@ __device__ __forceinline__ RowMeta load_meta_num(const int* rows, int q, int cou
 }
 
 // wave-per-row kernels: this lane's A entry of the row's first chunk, fetched one row ahead
-__device__ __forceinline__ PreA load_pre(const RowMeta& mtd, const int* JA, const float* VA, bool needVal) {
-  PreA p{0, 0.f, true};
+__device__ __forceinline__ PreA load_pre(const RowMeta& mtd, const int2* SBL, const float* VA, bool needVal) {
+  PreA p{0, 0, 0.f, true};
   const int ap = mtd.as + lane_id();
-  if (ap < mtd.ae) { p.j = JA[ap]; if (needVal) p.a = VA[ap]; }
+  if (ap < mtd.ae) { const int2 sbl = SBL[ap]; p.bs = sbl.x; p.len = sbl.y; if (needVal) p.a = VA[ap]; }
   return p;
 }
 
@@ -1089,8 +1108,8 @@ __device__ __forceinline__ PreA load_pre(const RowMeta& mtd, const int* JA, cons
 template <int NW, int TBL, int U>
 __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ binPtr, int bin,
                                                          const int* __restrict__ rowIds,
-                                                         const int* __restrict__ IA, const int* __restrict__ JA,
-                                                         const int* __restrict__ IB, const int* __restrict__ JB,
+                                                         const int* __restrict__ IA, const int2* __restrict__ SBL,
+                                                         const int* __restrict__ JB,
                                                          const int* __restrict__ rowFlops, int* __restrict__ IC,
                                                          int* __restrict__ err, int* __restrict__ qctr) {
   __shared__ __attribute__((aligned(16))) int keys[TBL];
@@ -1111,15 +1130,15 @@ __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ 
   RowMeta cur = load_meta_sym(rows, q, count, IA, rowFlops);
   // NW == 1: two rows of metadata and one row of A entries are in flight ahead of the row being processed
   RowMeta nxt = NW == 1 ? load_meta_sym(rows, q + stride, count, IA, rowFlops) : RowMeta{0, 0, 0, 0, 0};
-  PreA pc = NW == 1 ? load_pre(cur, JA, nullptr, false) : PreA{0, 0.f, false};
+  PreA pc = NW == 1 ? load_pre(cur, SBL, nullptr, false) : PreA{0, 0, 0.f, false};
   while (q < count) {
     int qn;
-    PreA pn{0, 0.f, false};
+    PreA pn{0, 0, 0.f, false};
     RowMeta nn{0, 0, 0, 0, 0};
     if (NW == 1) {
       qn = q + stride;
       nn = load_meta_sym(rows, qn + stride, count, IA, rowFlops);
-      pn = load_pre(nxt, JA, nullptr, false);
+      pn = load_pre(nxt, SBL, nullptr, false);
     } else {
       qn = next_row<QB>(qctr, &qslot, q);
       nxt = load_meta_sym(rows, qn, count, IA, rowFlops);
@@ -1130,7 +1149,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ 
     if (tid == 0) cnt_s = 0;
     __syncthreads();
     int mine = 0;
-    for_each_product<NW, U, false>(st, cur.as, cur.ae, JA, nullptr, IB, JB, nullptr,
+    for_each_product<NW, U, false>(st, cur.as, cur.ae, SBL, nullptr, JB, nullptr,
                                    [&](const auto& act, const auto& col, const auto& val) {
       mine += hash_insert_multi(keys, size, shift, act, col, reinterpret_cast<int*>(&st.dummy[lane_id()]), err);
     }, pc, err);
@@ -1152,9 +1171,9 @@ __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ 
 template <int NW, int TBL, int U>
 __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ binPtr, int bin,
                                                          const int* __restrict__ rowIds,
-                                                         const int* __restrict__ IA, const int* __restrict__ JA,
+                                                         const int* __restrict__ IA, const int2* __restrict__ SBL,
                                                          const float* __restrict__ VA,
-                                                         const int* __restrict__ IB, const int* __restrict__ JB,
+                                                         const int* __restrict__ JB,
                                                          const float* __restrict__ VB,
                                                          const int* __restrict__ IC, int* __restrict__ JC,
                                                          float* __restrict__ C, int* __restrict__ err,
@@ -1177,15 +1196,15 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
   int q = NW > 1 ? next_row<QB>(qctr, &qslot, -1) : (int)(blockIdx.x >> 3);
   RowMeta cur = load_meta_num(rows, q, count, IA, IC);
   RowMeta nxt = NW == 1 ? load_meta_num(rows, q + stride, count, IA, IC) : RowMeta{0, 0, 0, 0, 0};
-  PreA pc = NW == 1 ? load_pre(cur, JA, VA, true) : PreA{0, 0.f, false};
+  PreA pc = NW == 1 ? load_pre(cur, SBL, VA, true) : PreA{0, 0, 0.f, false};
   while (q < count) {
     int qn;
-    PreA pn{0, 0.f, false};
+    PreA pn{0, 0, 0.f, false};
     RowMeta nn{0, 0, 0, 0, 0};
     if (NW == 1) {
       qn = q + stride;
       nn = load_meta_num(rows, qn + stride, count, IA, IC);
-      pn = load_pre(nxt, JA, VA, true);
+      pn = load_pre(nxt, SBL, VA, true);
     } else {
       qn = next_row<QB>(qctr, &qslot, q);
       nxt = load_meta_num(rows, qn, count, IA, IC);
@@ -1198,7 +1217,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
     if (NW > 1 && tid == 0) emitted = 0;
     __syncthreads();
     if (!ABL(8))
-    for_each_product<NW, U, true>(st, cur.as, cur.ae, JA, VA, IB, JB, VB,
+    for_each_product<NW, U, true>(st, cur.as, cur.ae, SBL, VA, JB, VB,
                                   [&](const auto& act, const auto& col, const auto& val) {
       if (ABL(1)) {
 #pragma unroll
@@ -1304,8 +1323,8 @@ __device__ __forceinline__ int block_sum_16(int v, int* red) {
 // saveBitmaps: device buffer of saveCap row slots x BIG_WORDS words (may be null / 0); only used when n <= BIG_WC
 __global__ __launch_bounds__(BIG_THREADS) void k_sym_big(const int* __restrict__ binPtr, int bin,
                                                          const int* __restrict__ rowIds,
-                                                         const int* __restrict__ IA, const int* __restrict__ JA,
-                                                         const int* __restrict__ IB, const int* __restrict__ JB,
+                                                         const int* __restrict__ IA, const int2* __restrict__ SBL,
+                                                         const int* __restrict__ JB,
                                                          int n, int* __restrict__ IC,
                                                          unsigned* __restrict__ saveBitmaps, int saveCap,
                                                          int* __restrict__ qctr) {
@@ -1323,7 +1342,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sym_big(const int* __restrict__
       const int words4 = (words + 3) & ~3;             // the bitmap is cleared and counted four words at a time
       for (int i = tid * 4; i < words4; i += BIG_THREADS * 4) *reinterpret_cast<uint4*>(&sh.bitmap[i]) = make_uint4(0u, 0u, 0u, 0u);
       __syncthreads();
-      for_each_product<BIG_NW, BIG_U, false>(sh.st, as, ae, JA, nullptr, IB, JB, nullptr,
+      for_each_product<BIG_NW, BIG_U, false>(sh.st, as, ae, SBL, nullptr, JB, nullptr,
                                              [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&)[BIG_U]) {
 #pragma unroll
         for (int u = 0; u < BIG_U; ++u) {            // predicated by value: OR-ing 0 changes nothing
@@ -1351,9 +1370,9 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sym_big(const int* __restrict__
 // numeric A (n <= BIG_WC): rank kernel
 __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__ binPtr, int bin,
                                                          const int* __restrict__ rowIds,
-                                                         const int* __restrict__ IA, const int* __restrict__ JA,
+                                                         const int* __restrict__ IA, const int2* __restrict__ SBL,
                                                          const float* __restrict__ VA,
-                                                         const int* __restrict__ IB, const int* __restrict__ JB,
+                                                         const int* __restrict__ JB,
                                                          const float* __restrict__ VB, int n,
                                                          const int* __restrict__ IC, int* __restrict__ JC,
                                                          float* __restrict__ C, int* __restrict__ err,
@@ -1376,7 +1395,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
     } else {
       for (int i = tid; i < BIG_WORDS; i += BIG_THREADS) sh.bitmap[i] = 0u;
       __syncthreads();
-      for_each_product<BIG_NW, BIG_U, false>(sh.st, as, ae, JA, nullptr, IB, JB, nullptr,
+      for_each_product<BIG_NW, BIG_U, false>(sh.st, as, ae, SBL, nullptr, JB, nullptr,
                                              [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&)[BIG_U]) {
 #pragma unroll
         for (int u = 0; u < BIG_U; ++u) {
@@ -1437,7 +1456,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
       __syncthreads();
       for (int i = tid; i < span; i += BIG_THREADS) sh.acc[i] = 0.f;
       __syncthreads();
-      for_each_product<BIG_NW, BIG_U, true>(sh.st, as, ae, JA, VA, IB, JB, VB,
+      for_each_product<BIG_NW, BIG_U, true>(sh.st, as, ae, SBL, VA, JB, VB,
                                             [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&val)[BIG_U]) {
         int rk[BIG_U];
 #pragma unroll
@@ -1469,9 +1488,9 @@ __device__ __forceinline__ unsigned bh_class(int col, unsigned npass) {
 
 __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restrict__ binPtr, int bin,
                                                              const int* __restrict__ rowIds,
-                                                             const int* __restrict__ IA, const int* __restrict__ JA,
+                                                             const int* __restrict__ IA, const int2* __restrict__ SBL,
                                                              const float* __restrict__ VA,
-                                                             const int* __restrict__ IB, const int* __restrict__ JB,
+                                                             const int* __restrict__ JB,
                                                              const float* __restrict__ VB,
                                                              const int* __restrict__ IC, int* __restrict__ JC,
                                                              float* __restrict__ C, int* __restrict__ err,
@@ -1509,7 +1528,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
       if (pass == 0 && tid == 0) { sh.emitted = 0; sh.ovf = 0; }
       __syncthreads();
       if (pass == 0 || !useSpill) {
-        for_each_product<BIG_NW, BH_U, true>(sh.st, as, ae, JA, VA, IB, JB, VB,
+        for_each_product<BIG_NW, BH_U, true>(sh.st, as, ae, SBL, VA, JB, VB,
                                               [&](const bool (&act)[BH_U], const int (&col)[BH_U], const float (&val)[BH_U]) {
           bool mine[BH_U];
           unsigned cls[BH_U];

@@ -141,6 +141,8 @@ struct spgemm_handle {
   int* rowIds = nullptr;
   unsigned long long* tileSum = nullptr;
   unsigned long long* blockP = nullptr;     // per-block sums of row flops (reduced by k_bin_scan)
+  int2* sbl = nullptr;                       // per A entry {B-row start, B-row length} (k_entry_lens), cap_nnz entries
+  long long cap_nnz = -1;
   HostMirror* dsmall = nullptr;
   HostMirror* hsmall = nullptr;
   HostMirror mirror;                 // host copy taken at the end of the symbolic phase
@@ -173,6 +175,16 @@ static int ws_free(spgemm_handle* h) {
   hipFree(h->rowIds); hipFree(h->tileSum); hipFree(h->blockP);
   h->rowFlops = nullptr; h->binId = nullptr; h->blockHist = nullptr; h->blockOff = nullptr;
   h->rowIds = nullptr; h->tileSum = nullptr; h->blockP = nullptr; h->cap_m = -1;
+  return SPGEMM_OK;
+}
+
+static int ws_ensure_entries(spgemm_handle* h, long long nnzA) {
+  if (nnzA <= h->cap_nnz) return SPGEMM_OK;
+  hipFree(h->sbl);
+  h->sbl = nullptr; h->cap_nnz = -1;
+  const long long cap = nnzA + nnzA / 8 + 1024;
+  HIPCHK(hipMalloc((void**)&h->sbl, sizeof(int2) * (size_t)cap));
+  h->cap_nnz = cap;
   return SPGEMM_OK;
 }
 
@@ -252,6 +264,7 @@ extern "C" int spgemm_hip_destroy(spgemm_handle* h) {
   ws_free(h);
   hipFree(h->bigBitmaps);
   hipFree(h->spill);
+  hipFree(h->sbl);
   hipFree(h->dsmall);
   hipHostFree(h->hsmall);
   for (auto& e : h->ev) if (e) hipEventDestroy(e);
@@ -361,12 +374,19 @@ static void join_streams(spgemm_handle* h) {
   } while (0)
 
 // flops + bins: K1, K2, K3.  Also presets IC[row] for rows with 0 / 1 products.
-static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, int m, int* dIC) {
+// nnzA >= 0: the per-entry records h->sbl are (re)built first and the row sums read them; nnzA < 0 (entry points of
+// the C ABI that are not told nnz(A)): the sums gather through JA -> IB directly.
+static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, int m, long long nnzA, int* dIC) {
   const int nblk = cdiv(m, K1_THREADS);
   HIPCHK(hipMemsetAsync(h->dsmall, 0, sizeof(HostMirror), h->stream));
+  if (nnzA >= 0) CHK(ws_ensure_entries(h, nnzA));
   if (m > 0) {
     { KTimer t(h, SPGEMM_K_ROW_FLOPS);
-      hipLaunchKernelGGL(k_row_flops, dim3(nblk), dim3(K1_THREADS), 0, h->stream, m, dIA, dJA, dIB, h->rowFlops,
+      if (nnzA > 0)
+        hipLaunchKernelGGL(k_entry_lens, dim3(clampi(cdiv(nnzA, 256), 1, h->numCU * 32)), dim3(256), 0, h->stream, (int)nnzA,
+                           dJA, dIB, h->sbl);
+      hipLaunchKernelGGL(k_row_flops, dim3(nblk), dim3(K1_THREADS), 0, h->stream, m, dIA, dJA, dIB,
+                         nnzA >= 0 ? h->sbl : (const int2*)nullptr, h->rowFlops,
                          h->binId, h->blockHist, h->blockP, dIC); }
     { KTimer t(h, SPGEMM_K_BIN_SCAN);
       hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, h->stream, nblk, h->blockHist, h->blockOff,
@@ -381,8 +401,9 @@ static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, con
 
 // symbolic pass over bins 2..8 (bins 0/1 were preset by K1).  Bin sizes are not known on the host
 // here (no sync): grids are capped by the CU count and every block strides / dequeues over its bin.
-static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, const int* dJB,
+static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJB,
                            int m, int n, const int* rowIds, int* dIC) {
+  const int2* sbl = h->sbl;
   if (m <= 0) return SPGEMM_OK;
   const int* bp = h->dsmall->binPtr;
   int* err = &h->dsmall->err;
@@ -391,25 +412,25 @@ static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJA, con
   fork_streams(h);
   { hipStream_t st = h->side[3]; KTimer t(h, SPGEMM_K_SYM_BIG, st);
     hipLaunchKernelGGL(k_sym_big, dim3(clampi(m, 1, cu)), dim3(BIG_THREADS), sizeof(BigSymShared), st, bp, 8,
-                       rowIds, dIA, dJA, dIB, dJB, n, dIC, h->bigBitmaps, h->bm_cap, qc + 0); }
+                       rowIds, dIA, sbl, dJB, n, dIC, h->bigBitmaps, h->bm_cap, qc + 0); }
   { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_SYM_HASH8, st);
     LAUNCH_U(k_sym_hash, 8, 8192, dim3(clampi(m, 1, cu * 3)), dim3(512), st, bp, 7, rowIds, dIA,
-             dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 1); }
+             sbl, dJB, h->rowFlops, dIC, err, qc + 1); }
   { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_SYM_HASH4, st);
     LAUNCH_U(k_sym_hash, 4, 4096, dim3(clampi(m, 1, cu * 8)), dim3(256), st, bp, 6, rowIds, dIA,
-             dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 2); }
+             sbl, dJB, h->rowFlops, dIC, err, qc + 2); }
   { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_SYM_HASH1, st);
     const int* sb = h->dsmall->slotBase;         // bin 5 = two layout slots: table 512 up to 256 products, 1024 above
     LAUNCH_U(k_sym_hash, 1, 512, dim3(grid8(m, cu * h->h1sym)), dim3(64), st, sb, SLOT_H1A, rowIds, dIA,
-             dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 3);
+             sbl, dJB, h->rowFlops, dIC, err, qc + 3);
     LAUNCH_U(k_sym_hash, 1, 1024, dim3(grid8(m, cu * h->h1sym)), dim3(64), st, sb, SLOT_H1B, rowIds, dIA,
-             dJA, dIB, dJB, h->rowFlops, dIC, err, qc + 3); }
+             sbl, dJB, h->rowFlops, dIC, err, qc + 3); }
   { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_SYM_G16, st);
     hipLaunchKernelGGL((k_sym_g16<128, 4>), dim3(grid8(cdiv(m, 16), cu * 16)), dim3(256), 0, st, bp, 4,
-                       rowIds, dIA, dJA, dIB, dJB, h->rowFlops, dIC, err); }
+                       rowIds, dIA, sbl, dJB, h->rowFlops, dIC, err); }
   { KTimer t(h, SPGEMM_K_SYM_SMALL4);
     hipLaunchKernelGGL((k_sym_small<4, 32>), dim3(grid8(cdiv(m, 64), cu * 8)), dim3(256), 0, h->stream, bp, 2, 4,
-                       rowIds, dIA, dJA, dIB, dJB, h->rowFlops, dIC, err); }
+                       rowIds, dIA, sbl, dJB, h->rowFlops, dIC, err); }
   join_streams(h);
   HIPCHK(hipGetLastError());
   return SPGEMM_OK;
@@ -426,9 +447,10 @@ static int launch_scan(spgemm_handle* h, int* cnt, int m, unsigned long long* dT
   return SPGEMM_OK;
 }
 
-static int launch_numeric(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, const int* dIB,
+static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
                           const int* dJB, const float* dB, int n, const int* rowIds, const int* hostBinPtr,
                           const int* dIC, int* dJC, float* dC) {
+  const int2* sbl = h->sbl;
   const int* bp = h->dsmall->binPtr;
   int* err = &h->dsmall->err;
   int* qc = h->dsmall->qctr;
@@ -439,7 +461,7 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const int* dJA, cons
     hipStream_t st = h->side[3];
     if (n <= BIG_WC) { KTimer t(h, SPGEMM_K_NUM_BIG, st);
       hipLaunchKernelGGL(k_num_big, dim3(clampi(rows(8, 9), 1, cu)), dim3(BIG_THREADS), sizeof(BigNumShared), st,
-                         bp, 8, rowIds, dIA, dJA, dA, dIB, dJB, dB, n, dIC, dJC, dC, err, h->bigBitmaps, h->bm_cap,
+                         bp, 8, rowIds, dIA, sbl, dA, dJB, dB, n, dIC, dJC, dC, err, h->bigBitmaps, h->bm_cap,
                          qc + 4);
     } else { KTimer t(h, SPGEMM_K_NUM_BIGHASH, st);
       const int blocks = clampi(rows(8, 9), 1, cu);
@@ -451,29 +473,29 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const int* dJA, cons
         else (void)hipGetLastError();                  // without it those rows walk once per pass
       }
       hipLaunchKernelGGL(k_num_bighash, dim3(blocks), dim3(BIG_THREADS), sizeof(BigHashShared), st,
-                         bp, 8, rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 4, h->rowFlops,
+                         bp, 8, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 4, h->rowFlops,
                          h->spill_blocks >= blocks ? h->spill : (int2*)nullptr, BH_SPILL, h->bhCap, h->bhMargin); }
   }
   if (rows(7, 8) > 0) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_NUM_HASH8, st);
     LAUNCH_U(k_num_hash, 8, 8192, dim3(clampi(rows(7, 8), 1, cu * 2)), dim3(512), st, bp, 7,
-             rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 5); }
+             rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 5); }
   if (rows(6, 7) > 0) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_NUM_HASH4, st);
     LAUNCH_U(k_num_hash, 4, 4096, dim3(clampi(rows(6, 7), 1, cu * 4)), dim3(256), st, bp, 6,
-             rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 6); }
+             rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 6); }
   if (rows(5, 6) > 0) { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_NUM_HASH1, st);
     const int* sb = h->dsmall->slotBase;
     const int* hs_ = h->mirror.slotBase;
     const int na = hs_[SLOT_H1A + 1] - hs_[SLOT_H1A], nb = hs_[SLOT_H1B + 1] - hs_[SLOT_H1B];
     if (na > 0) LAUNCH_U(k_num_hash, 1, 512, dim3(grid8(na, cu * 24)), dim3(64), st, sb, SLOT_H1A,
-                         rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 7);
+                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7);
     if (nb > 0) LAUNCH_U(k_num_hash, 1, 1024, dim3(grid8(nb, cu * 16)), dim3(64), st, sb, SLOT_H1B,
-                         rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err, qc + 7); }
+                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7); }
   if (rows(4, 5) > 0) { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_NUM_G16, st);
     hipLaunchKernelGGL((k_num_g16<128, 4>), dim3(grid8(cdiv(rows(4, 5), 16), cu * 16)), dim3(256), 0, st,
-                       bp, 4, rowIds, dIA, dJA, dA, dIB, dJB, dB, dIC, dJC, dC, err); }
+                       bp, 4, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err); }
   if (rows(1, 4) > 0) { KTimer t(h, SPGEMM_K_NUM_SMALL4);
     hipLaunchKernelGGL((k_num_small<4, 32>), dim3(grid8(cdiv(rows(1, 4), 64), cu * 8)), dim3(256), 0, h->stream, bp,
-                       1, 4, rowIds, dIA, dJA, dA, dIB, dJB, dB, h->rowFlops, dIC, dJC, dC, err); }
+                       1, 4, rowIds, dIA, sbl, dA, dJB, dB, h->rowFlops, dIC, dJC, dC, err); }
   join_streams(h);
   HIPCHK(hipGetLastError());
   return SPGEMM_OK;
@@ -492,7 +514,7 @@ struct PreClass { const int* drowIds; const int* hv; const int* dflops; };
 static int unpack_classification(spgemm_handle* h, int m, const PreClass& pre, int* dIC);
 
 // phase 1: classify + symbolic + scan; one host sync at the end (nnzC, bin sizes, error flags)
-static int symbolic_phase(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, const int* dJB,
+static int symbolic_phase(spgemm_handle* h, const int* dIA, const int* dJA, int nnzA, const int* dIB, const int* dJB,
                           int m, int k, int n, const PreClass* pre, int* dIC, int* nnzCp) {
   (void)k;
   hipStream_t s = h->stream;
@@ -501,11 +523,14 @@ static int symbolic_phase(spgemm_handle* h, const int* dIA, const int* dJA, cons
   if (pre) {
     CHK(unpack_classification(h, m, *pre, dIC));
     h->cur_rowIds = pre->drowIds;
+    CHK(ws_ensure_entries(h, nnzA));                 // the caller's classification carries no per-entry records
+    if (nnzA > 0)
+      hipLaunchKernelGGL(k_entry_lens, dim3(clampi(cdiv(nnzA, 256), 1, h->numCU * 32)), dim3(256), 0, s, nnzA, dJA, dIB, h->sbl);
   } else {
-    CHK(launch_classify(h, dIA, dJA, dIB, m, dIC));
+    CHK(launch_classify(h, dIA, dJA, dIB, m, nnzA, dIC));
   }
   hipEventRecord(h->ev[1], s);
-  CHK(launch_symbolic(h, dIA, dJA, dIB, dJB, m, n, h->cur_rowIds, dIC));
+  CHK(launch_symbolic(h, dIA, dJB, m, n, h->cur_rowIds, dIC));
   hipEventRecord(h->ev[2], s);
   if (m > 0) CHK(launch_scan(h, dIC, m, &h->dsmall->nnzC64));
   else HIPCHK(hipMemsetAsync(dIC, 0, sizeof(int), s));
@@ -541,7 +566,7 @@ static int numeric_phase(spgemm_handle* h, const int* dIA, const int* dJA, const
   hipEventRecord(h->ev[4], s);
   if (m > 0 && nnzC > 0) {
     if (!dJC || !dC) return fail(SPGEMM_ERR_ARG, "output buffers are null");
-    CHK(launch_numeric(h, dIA, dJA, dA, dIB, dJB, dB, n, h->cur_rowIds, h->mirror.binPtr, dIC, dJC, dC));
+    CHK(launch_numeric(h, dIA, dA, dJB, dB, n, h->cur_rowIds, h->mirror.binPtr, dIC, dJC, dC));
   }
   hipEventRecord(h->ev[5], s);
   if (hipMemcpyAsync(&h->hsmall->err, &h->dsmall->err, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -584,7 +609,7 @@ static int spgemm_device(spgemm_handle* h, const int* dIA, const int* dJA, const
   auto cleanup = [&](int rc) { pool().release(dIC); pool().release(dJC); pool().release(dC); return rc; };
   HIPCHK(pool().alloc((void**)&dIC, sizeof(int) * ((size_t)m + 1)));
   int nnzC = 0;
-  int rc = symbolic_phase(h, dIA, dJA, dIB, dJB, m, k, n, pre, dIC, &nnzC);
+  int rc = symbolic_phase(h, dIA, dJA, nnzA, dIB, dJB, m, k, n, pre, dIC, &nnzC);
   if (rc) return cleanup(rc);
   if (hipSuccess != pool().alloc((void**)&dJC, sizeof(int) * (size_t)std::max(nnzC, 1)) ||
       hipSuccess != pool().alloc((void**)&dC, sizeof(float) * (size_t)std::max(nnzC, 1)))
@@ -610,7 +635,7 @@ extern "C" int hip_spgemm_symbolic(spgemm_handle* h, const int* dIA, const int* 
   CHK(check_common(dIB, dJB, dJB, nnzB, "B"));
   HIPCHK(hipSetDevice(h->device));
   CHK(ws_ensure(h, m));
-  return symbolic_phase(h, dIA, dJA, dIB, dJB, m, k, n, nullptr, dIC, nnzC);
+  return symbolic_phase(h, dIA, dJA, nnzA, dIB, dJB, m, k, n, nullptr, dIC, nnzC);
 }
 
 extern "C" int hip_spgemm_numeric(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, int nnzA,
@@ -633,7 +658,7 @@ extern "C" int hip_csr_row_flops(spgemm_handle* h, const int* dIA, const int* dJ
   CHK(ws_ensure(h, m));
   int* tmpIC = nullptr;
   HIPCHK(pool().alloc((void**)&tmpIC, sizeof(int) * ((size_t)m + 1)));
-  int rc = launch_classify(h, dIA, dJA, dIB, m, tmpIC);
+  int rc = launch_classify(h, dIA, dJA, dIB, m, -1, tmpIC);
   if (rc == SPGEMM_OK && m > 0 &&
       hipMemcpyAsync(dRowFlops, h->rowFlops, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
     rc = fail(SPGEMM_ERR_HIP, "copy of row flops failed");
@@ -684,7 +709,7 @@ extern "C" int hip_gpuFlopsClassify(spgemm_handle* h, const int* dIA, const int*
   if (hipSuccess != pool().alloc((void**)&fl, sizeof(int) * ((size_t)m + 1)) ||
       hipSuccess != pool().alloc((void**)&tmpIC, sizeof(int) * ((size_t)m + 1)))
     return cleanup(fail(SPGEMM_ERR_HIP, "device allocation failed"));
-  int rc = launch_classify(h, dIA, dJA, dIB, m, tmpIC);
+  int rc = launch_classify(h, dIA, dJA, dIB, m, -1, tmpIC);
   if (rc) return cleanup(rc);
   hipStream_t s = h->stream;
   if (m > 0) {
