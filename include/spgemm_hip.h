@@ -69,6 +69,10 @@ int  spgemm_hip_create(spgemm_handle** h, int device);   /* hipSetDevice(device)
 int  spgemm_hip_destroy(spgemm_handle* h);
 int  spgemm_hip_get_stats(const spgemm_handle* h, spgemm_stats* out);
 void* spgemm_hip_stream(spgemm_handle* h);        /* hipStream_t the kernels run on (for event timing) */
+/* Per-kernel HIP-event timing (spgemm_stats.ms_kernel): bit i of `mask` brackets the launches of kernel SPGEMM_K_<i>
+ * with two events on the handle's stream.  Off by default (an event record costs stream time); bench.py turns on the
+ * dominant kernel inside the timed region and all kernels in a separate, untimed pass. */
+int  spgemm_hip_set_kernel_timing(spgemm_handle* h, unsigned mask);
 
 /* ---- device memory: replaces the cudaMalloc/cudaMemcpy/cudaFree inside
  *      CSR::toGpuCSR / toCpuCSR / deviceDispose  (nlibs/CSR.cc:342-379) ------------------------- */

@@ -150,6 +150,9 @@ struct spgemm_handle {
   int sym_m = -1;                    // rows of the pending symbolic phase, -1 = none
   hipEvent_t kev[2 * SPGEMM_NKERNELS];
   bool kused[SPGEMM_NKERNELS];
+  unsigned ktiming = 0;              // bit i: launches of kernel i are bracketed by events (spgemm_hip_set_kernel_timing)
+  hipEvent_t evMid = nullptr;        // "classification is on the host" marker of the one-shot path
+  HostMirror* hmid = nullptr;        // pinned copy taken right after the classify kernels
   // side streams: the per-bin kernels of one phase are independent; SPGEMM_CONCURRENT=1 runs them concurrently
   // (default off: the 155 KB-LDS big-row kernel owns the CUs it runs on, overlap measured slower than serial)
   static constexpr int NSIDE = 4;
@@ -247,6 +250,9 @@ extern "C" int spgemm_hip_create(spgemm_handle** out, int device) {
   for (auto& e : h->join_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(hipMalloc((void**)&h->dsmall, sizeof(HostMirror)));
   HIPCHK(hipHostMalloc((void**)&h->hsmall, sizeof(HostMirror), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&h->hmid, sizeof(HostMirror), hipHostMallocDefault));
+  HIPCHK(hipEventCreateWithFlags(&h->evMid, hipEventDisableTiming));
+  { const char* e = getenv("SPGEMM_KTIMING"); if (e) h->ktiming = (unsigned)strtoul(e, nullptr, 0); }
   memset(&h->stats, 0, sizeof(h->stats));
   // the big-row kernels use more than the default 64 KB of dynamic LDS
   HIPCHK(hipFuncSetAttribute((const void*)k_sym_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigSymShared)));
@@ -267,6 +273,8 @@ extern "C" int spgemm_hip_destroy(spgemm_handle* h) {
   hipFree(h->sbl);
   hipFree(h->dsmall);
   hipHostFree(h->hsmall);
+  hipHostFree(h->hmid);
+  if (h->evMid) hipEventDestroy(h->evMid);
   for (auto& e : h->ev) if (e) hipEventDestroy(e);
   for (auto& e : h->kev) if (e) hipEventDestroy(e);
   if (h->fork_ev) hipEventDestroy(h->fork_ev);
@@ -283,6 +291,12 @@ extern "C" int spgemm_hip_get_stats(const spgemm_handle* h, spgemm_stats* out) {
 }
 
 extern "C" void* spgemm_hip_stream(spgemm_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+extern "C" int spgemm_hip_set_kernel_timing(spgemm_handle* h, unsigned mask) {
+  if (!h) return fail(SPGEMM_ERR_ARG, "null handle");
+  h->ktiming = mask;
+  return SPGEMM_OK;
+}
 
 static std::mutex g_default_mu;
 static spgemm_handle* g_default = nullptr;
@@ -335,12 +349,15 @@ static const char* kKernelNames[SPGEMM_NKERNELS] = {
 extern "C" const char* spgemm_hip_kernel_name(int id) { return (id >= 0 && id < SPGEMM_NKERNELS) ? kKernelNames[id] : ""; }
 
 // every launch is bracketed by two events on its stream (per-kernel durations for bench.py's roofline)
+// (only for the kernels selected with spgemm_hip_set_kernel_timing: an event record costs a few microseconds of
+// stream time, 40 of them per SpGEMM were 3 % of a step)
 struct KTimer {
-  spgemm_handle* h; int id; hipStream_t s;
-  KTimer(spgemm_handle* h_, int id_, hipStream_t s_ = nullptr) : h(h_), id(id_), s(s_ ? s_ : h_->stream) {
-    hipEventRecord(h->kev[2 * id], s); h->kused[id] = true;
+  spgemm_handle* h; int id; hipStream_t s; bool on;
+  KTimer(spgemm_handle* h_, int id_, hipStream_t s_ = nullptr)
+      : h(h_), id(id_), s(s_ ? s_ : h_->stream), on((h_->ktiming >> id_) & 1u) {
+    if (on) { hipEventRecord(h->kev[2 * id], s); h->kused[id] = true; }
   }
-  ~KTimer() { hipEventRecord(h->kev[2 * id + 1], s); }
+  ~KTimer() { if (on) hipEventRecord(h->kev[2 * id + 1], s); }
 };
 
 static void collect_kernel_times(spgemm_handle* h, bool reset) {
@@ -557,6 +574,18 @@ static int symbolic_phase(spgemm_handle* h, const int* dIA, const int* dJA, int 
   return SPGEMM_OK;
 }
 
+// room for the big rows' bitmaps next time (rank kernel only)
+static void grow_bitmaps(spgemm_handle* h, int n) {
+  const int nbig = h->mirror.binPtr[NBINS] - h->mirror.binPtr[NBINS - 1];
+  if (n <= BIG_WC && nbig > h->bm_cap) {
+    hipFree(h->bigBitmaps);
+    h->bigBitmaps = nullptr;
+    const int cap = nbig + nbig / 4 + 16;
+    if (hipMalloc((void**)&h->bigBitmaps, (size_t)cap * BIG_WORDS * sizeof(unsigned)) == hipSuccess) h->bm_cap = cap;
+    else { h->bm_cap = 0; (void)hipGetLastError(); }
+  }
+}
+
 // phase 2: numeric into caller-provided dJC/dC; one host sync at the end (error flags)
 static int numeric_phase(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, const int* dIB,
                          const int* dJB, const float* dB, int m, int n, const int* dIC, int* dJC, float* dC) {
@@ -580,15 +609,7 @@ static int numeric_phase(spgemm_handle* h, const int* dIA, const int* dJA, const
   hipEventElapsedTime(&st.ms_numeric, h->ev[4], h->ev[5]);
   st.ms_total += st.ms_numeric;
   collect_kernel_times(h, false);
-  // room for the big rows' bitmaps next time (rank kernel only)
-  const int nbig = h->mirror.binPtr[NBINS] - h->mirror.binPtr[NBINS - 1];
-  if (n <= BIG_WC && nbig > h->bm_cap) {
-    hipFree(h->bigBitmaps);
-    h->bigBitmaps = nullptr;
-    const int cap = nbig + nbig / 4 + 16;
-    if (hipMalloc((void**)&h->bigBitmaps, (size_t)cap * BIG_WORDS * sizeof(unsigned)) == hipSuccess) h->bm_cap = cap;
-    else { h->bm_cap = 0; (void)hipGetLastError(); }
-  }
+  grow_bitmaps(h, n);
   return SPGEMM_OK;
 }
 
@@ -609,6 +630,83 @@ static int spgemm_device(spgemm_handle* h, const int* dIA, const int* dJA, const
   auto cleanup = [&](int rc) { pool().release(dIC); pool().release(dJC); pool().release(dC); return rc; };
   HIPCHK(pool().alloc((void**)&dIC, sizeof(int) * ((size_t)m + 1)));
   int nnzC = 0;
+  if (!pre && m > 0) {
+    // One-shot path, no host round trip between the phases: the classification (bin sizes, P) is copied to the host
+    // while the symbolic kernels run; colInd/values are allocated with P entries (an upper bound of nnz(C), 8*P bytes --
+    // HBM is 288 GB) so that the numeric kernels can be queued right behind the scan; nnz(C) and the error flags are
+    // read once, at the end.  A product with P beyond the bound below takes the two-phase path.
+    hipStream_t s = h->stream;
+    hipEventRecord(h->ev[0], s);
+    h->cur_rowIds = h->rowIds;
+    int rc = launch_classify(h, dIA, dJA, dIB, m, nnzA, dIC);
+    if (rc) return cleanup(rc);
+    hipEventRecord(h->ev[1], s);
+    if (hipMemcpyAsync(h->hmid, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipEventRecord(h->evMid, s) != hipSuccess)
+      return cleanup(fail(SPGEMM_ERR_HIP, "classification copy failed: %s", hipGetErrorString(hipGetLastError())));
+    if ((rc = launch_symbolic(h, dIA, dJB, m, n, h->cur_rowIds, dIC))) return cleanup(rc);
+    hipEventRecord(h->ev[2], s);
+    if ((rc = launch_scan(h, dIC, m, &h->dsmall->nnzC64))) return cleanup(rc);
+    hipEventRecord(h->ev[3], s);
+    if (hipEventSynchronize(h->evMid) != hipSuccess)
+      return cleanup(fail(SPGEMM_ERR_HIP, "classification failed: %s", hipGetErrorString(hipGetLastError())));
+    const HostMirror mid = *h->hmid;
+    const unsigned long long P = mid.totalP;
+    if (P <= (1ull << 30)) {
+      const size_t capC = (size_t)std::max<unsigned long long>(P, 1ull);
+      if (hipSuccess != pool().alloc((void**)&dJC, sizeof(int) * capC) ||
+          hipSuccess != pool().alloc((void**)&dC, sizeof(float) * capC))
+        return cleanup(fail(SPGEMM_ERR_HIP, "device allocation of C (%llu entries) failed", P));
+      hipEventRecord(h->ev[4], s);
+      h->mirror = mid;                                 // bin sizes for the numeric launch grids
+      if (P > 0 && (rc = launch_numeric(h, dIA, dA, dJB, dB, n, h->cur_rowIds, mid.binPtr, dIC, dJC, dC))) return cleanup(rc);
+      hipEventRecord(h->ev[5], s);
+      if (hipMemcpyAsync(h->hsmall, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
+          hipStreamSynchronize(s) != hipSuccess)
+        return cleanup(fail(SPGEMM_ERR_HIP, "SpGEMM failed: %s", hipGetErrorString(hipGetLastError())));
+      h->mirror = *h->hsmall;
+      h->sym_m = -1;
+      const HostMirror& hm = h->mirror;
+#ifndef SMF_ABLATE
+      if (hm.err) return cleanup(fail(SPGEMM_ERR_INTERNAL, "device invariant broken (flags=%d)", hm.err));
+#endif
+      if (hm.nnzC64 > 0x7fffffffULL) return cleanup(fail(SPGEMM_ERR_OVERFLOW, "nnz(C)=%llu does not fit int32 CSR", hm.nnzC64));
+      spgemm_stats& st = h->stats;
+      st.total_flops = (long long)hm.totalP;
+      st.nnzC = (int)hm.nnzC64;
+      for (int b = 0; b < NBINS; ++b) st.bin_rows[b] = hm.binPtr[b + 1] - hm.binPtr[b];
+      hipEventElapsedTime(&st.ms_classify, h->ev[0], h->ev[1]);
+      hipEventElapsedTime(&st.ms_symbolic, h->ev[1], h->ev[2]);
+      hipEventElapsedTime(&st.ms_scan_alloc, h->ev[2], h->ev[4]);
+      hipEventElapsedTime(&st.ms_numeric, h->ev[4], h->ev[5]);
+      hipEventElapsedTime(&st.ms_total, h->ev[0], h->ev[5]);
+      collect_kernel_times(h, true);
+      grow_bitmaps(h, n);
+      *dICp = dIC; *dJCp = dJC; *dCp = dC; *nnzCp = (int)hm.nnzC64;
+      return SPGEMM_OK;
+    }
+    // P too large for a speculative allocation: finish the symbolic phase the two-phase way (kernels already queued)
+    if (hipMemcpyAsync(h->hsmall, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+      return cleanup(fail(SPGEMM_ERR_HIP, "symbolic phase failed: %s", hipGetErrorString(hipGetLastError())));
+    h->mirror = *h->hsmall;
+    if (h->mirror.err) return cleanup(fail(SPGEMM_ERR_INTERNAL, "device invariant broken in symbolic phase (flags=%d)", h->mirror.err));
+    if (h->mirror.nnzC64 > 0x7fffffffULL) return cleanup(fail(SPGEMM_ERR_OVERFLOW, "nnz(C)=%llu does not fit int32 CSR", h->mirror.nnzC64));
+    h->stats.total_flops = (long long)h->mirror.totalP;
+    h->stats.nnzC = (int)h->mirror.nnzC64;
+    for (int b = 0; b < NBINS; ++b) h->stats.bin_rows[b] = h->mirror.binPtr[b + 1] - h->mirror.binPtr[b];
+    h->stats.ms_total = 0.f;
+    collect_kernel_times(h, true);
+    h->sym_m = m;
+    nnzC = (int)h->mirror.nnzC64;
+    if (hipSuccess != pool().alloc((void**)&dJC, sizeof(int) * (size_t)std::max(nnzC, 1)) ||
+        hipSuccess != pool().alloc((void**)&dC, sizeof(float) * (size_t)std::max(nnzC, 1)))
+      return cleanup(fail(SPGEMM_ERR_HIP, "device allocation of C (%d entries) failed", nnzC));
+    rc = numeric_phase(h, dIA, dJA, dA, dIB, dJB, dB, m, n, dIC, dJC, dC);
+    if (rc) return cleanup(rc);
+    *dICp = dIC; *dJCp = dJC; *dCp = dC; *nnzCp = nnzC;
+    return SPGEMM_OK;
+  }
   int rc = symbolic_phase(h, dIA, dJA, nnzA, dIB, dJB, m, k, n, pre, dIC, &nnzC);
   if (rc) return cleanup(rc);
   if (hipSuccess != pool().alloc((void**)&dJC, sizeof(int) * (size_t)std::max(nnzC, 1)) ||

@@ -52,10 +52,13 @@ def _ptr(t):
 class HipEngine:
     """Local compute on one GPU through the C ABI (no CPU fallback)."""
 
-    def __init__(self, device_index):
+    def __init__(self, device_index, handles=1):
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
-        self.handle = hs.Handle(device_index)
+        # a handle keeps ONE pending symbolic phase; the sub-blocks of a sharded step need one each
+        self.handles = [hs.Handle(device_index) for _ in range(max(1, int(handles)))]
+        self.handle = self.handles[0]
+        self._last = None
 
     def tensor(self, arr, dtype):
         return torch.from_numpy(np.ascontiguousarray(arr)).to(dtype).to(self.device)
@@ -73,18 +76,27 @@ class HipEngine:
         hs.row_flops_raw(self.handle, _ptr(A["rowPtr"]), _ptr(A["colInd"]), _ptr(B["rowPtr"]), A["rows"], _ptr(out))
         return out.cpu().numpy().astype(np.int64)
 
-    def symbolic(self, A, B):
+    def symbolic(self, A, B, slot=0):
         IC = self.empty(A["rows"] + 1, torch.int32)
         self.sync()
-        nnz = hs.spgemm_symbolic_raw(self.handle, _ptr(A["rowPtr"]), _ptr(A["colInd"]), A["nnz"], _ptr(B["rowPtr"]),
+        nnz = hs.spgemm_symbolic_raw(self.handles[slot], _ptr(A["rowPtr"]), _ptr(A["colInd"]), A["nnz"], _ptr(B["rowPtr"]),
                                      _ptr(B["colInd"]), B["nnz"], A["rows"], A["cols"], B["cols"], _ptr(IC))
         return IC, nnz
 
-    def numeric(self, A, B, IC, JC_out, C_out):
+    def numeric(self, A, B, IC, JC_out, C_out, slot=0):
         self.sync()
-        hs.spgemm_numeric_raw(self.handle, _ptr(A["rowPtr"]), _ptr(A["colInd"]), _ptr(A["values"]), A["nnz"],
+        hs.spgemm_numeric_raw(self.handles[slot], _ptr(A["rowPtr"]), _ptr(A["colInd"]), _ptr(A["values"]), A["nnz"],
                               _ptr(B["rowPtr"]), _ptr(B["colInd"]), _ptr(B["values"]), B["nnz"], A["rows"], A["cols"],
                               B["cols"], _ptr(IC), _ptr(JC_out), _ptr(C_out))
+
+    def spmm(self, A, B):
+        """One-shot C = A*B (hip_gpuSpMM: classify, symbolic, scan, numeric with no host round trip in between).
+        Returns a DeviceCSR that owns the library's output arrays (released when dropped)."""
+        self.sync()
+        ic, jc, cv, nnz = hs.gpu_spmm_raw(self.handle, _ptr(A["rowPtr"]), _ptr(A["colInd"]), _ptr(A["values"]), A["nnz"],
+                                          _ptr(B["rowPtr"]), _ptr(B["colInd"]), _ptr(B["values"]), B["nnz"],
+                                          A["rows"], A["cols"], B["cols"])
+        return DeviceCSR(ic, jc, cv, A["rows"], B["cols"], nnz)
 
     def expand_prune(self, A, B):
         """One R-MCL step on this rank's rows: C = A*B (hip_gpuSpMM), then inflate/prune/normalise + compaction
@@ -114,6 +126,29 @@ class HipEngine:
         return self.handle.stats()
 
 
+class DeviceCSR:
+    """C arrays allocated by the library (spgemm_hip_malloc pool); freed back to the pool on release()/GC."""
+
+    def __init__(self, ic, jc, cv, rows, cols, nnz):
+        self.ic, self.jc, self.cv, self.rows, self.cols, self.nnz = ic, jc, cv, rows, cols, nnz
+
+    def to_host(self):
+        return (hs.d2h(self.ic, self.rows + 1, np.int32), hs.d2h(self.jc, self.nnz, np.int32),
+                hs.d2h(self.cv, self.nnz, np.float32))
+
+    def release(self):
+        for p in (self.ic, self.jc, self.cv):
+            if p:
+                hs.dev_free(p)
+        self.ic = self.jc = self.cv = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 def make_matrix(engine, rowPtr, colInd, values, rows, cols):
     return {"rowPtr": engine.tensor(rowPtr, torch.int32), "colInd": engine.tensor(colInd, torch.int32),
             "values": engine.tensor(values, torch.float32), "rows": int(rows), "cols": int(cols),
@@ -121,11 +156,17 @@ def make_matrix(engine, rowPtr, colInd, values, rows, cols):
 
 
 class ShardedSpGEMM:
-    """C = A * B with A row-sharded over the process group.  Every rank ends up with the whole C."""
+    """C = A * B with A row-sharded over the process group.  Every rank ends up with the whole C.
 
-    def __init__(self, engine, A_host, B_host=None, group=None):
+    A rank's row block is cut once more into `chunks` flops-balanced sub-blocks.  Per step: symbolic of every sub-block
+    (sizes) -> one all-gather of the sizes -> numeric of sub-block k straight into its slice of the gathered arrays, and
+    while sub-block k+1 computes, the send/recv pairs of sub-block k are in flight (RCCL runs on its own stream): the
+    exchange hides behind the compute instead of following it.  The gathered buffers are kept across steps."""
+
+    def __init__(self, engine, A_host, B_host=None, group=None, chunks=1, partition="flops"):
         """A_host/B_host: (rowPtr, colInd, values, rows, cols) numpy tuples, identical on every rank.
-        B_host=None means C = A*A (B is the replicated full A)."""
+        B_host=None means C = A*A (B is the replicated full A).  partition: "flops" (arrayEqualPartition64) or
+        "footprint" (flops + output-size estimate, static_omp_csr_kernel.cc:28-95 -> footprint_partition)."""
         self.engine = engine
         self.group = group
         self.world = dist.get_world_size(group) if (dist and dist.is_initialized()) else 1
@@ -140,42 +181,123 @@ class ShardedSpGEMM:
         self.total_flops = int(flops.sum())
         prefix = np.zeros(self.m + 1, dtype=np.int64)
         np.cumsum(flops, out=prefix[1:])
+        self.prefix = prefix
         self.ends = equal_partition64(prefix, self.world)
         r0, r1 = int(self.ends[self.rank]), int(self.ends[self.rank + 1])
         self.r0, self.r1 = r0, r1
         self.local_flops = int(prefix[r1] - prefix[r0])
         rpA = np.asarray(rpA)
+        ciA, vA = np.asarray(ciA), np.asarray(vA)
         lo, hi = int(rpA[r0]), int(rpA[r1])
-        self.A_local = make_matrix(engine, (rpA[r0:r1 + 1] - lo).astype(np.int32), np.asarray(ciA)[lo:hi],
-                                   np.asarray(vA)[lo:hi], r1 - r0, self.k)
+        self.A_local = make_matrix(engine, (rpA[r0:r1 + 1] - lo).astype(np.int32), ciA[lo:hi], vA[lo:hi], r1 - r0, self.k)
+        # sub-blocks of every rank (all ranks know all cuts: the receive side needs the row ranges of its peers)
+        self.chunks = max(1, min(int(chunks), len(getattr(engine, "handles", [None]))))
+        self.sub_ends = []                                   # per rank: chunks+1 global row indices
+        for r in range(self.world):
+            a0, a1 = int(self.ends[r]), int(self.ends[r + 1])
+            cut = equal_partition64(prefix[a0:a1 + 1] - prefix[a0], self.chunks) + a0 if a1 > a0 else \
+                np.full(self.chunks + 1, a0, dtype=np.int64)
+            self.sub_ends.append(cut)
+        self.A_sub = []
+        if self.world > 1 and self.chunks > 1:
+            for c in range(self.chunks):
+                s0, s1 = int(self.sub_ends[self.rank][c]), int(self.sub_ends[self.rank][c + 1])
+                lo, hi = int(rpA[s0]), int(rpA[s1])
+                self.A_sub.append(make_matrix(engine, (rpA[s0:s1 + 1] - lo).astype(np.int32), ciA[lo:hi], vA[lo:hi],
+                                              s1 - s0, self.k))
+        else:
+            self.chunks = 1
+            self.sub_ends = [np.array([int(self.ends[r]), int(self.ends[r + 1])], dtype=np.int64) for r in range(self.world)]
+            self.A_sub = [self.A_local]
+        self._buf = None                                     # gathered rowPtr / colInd / values, reused across steps
         del fullA
 
     # ---- one hot-path pass --------------------------------------------------------------------
     def step(self, gather=True):
         """gather=True: every rank returns the whole C (rowPtr, colInd, values).  gather=False: C stays row-sharded
-        like A — returns this rank's (local rowPtr, colInd, values) and no collective runs."""
-        eng, G, me = self.engine, self.world, self.rank
-        IC_loc, nnz_loc = eng.symbolic(self.A_local, self.B)
+        like A -- returns this rank's (local rowPtr, colInd, values) and no collective runs."""
+        eng, G, me, K = self.engine, self.world, self.rank, self.chunks
         if G == 1 or not gather:
+            if hasattr(eng, "spmm"):                          # one-shot entry point: no host round trip between the phases
+                self._last = None                            # the consumer is done with the previous C: back to the pool
+                out = eng.spmm(self.A_local, self.B)
+                self._last = out
+                return out
+            IC_loc, nnz_loc = eng.symbolic(self.A_local, self.B)
             JC = eng.empty(max(nnz_loc, 1), torch.int32)
             Cv = eng.empty(max(nnz_loc, 1), torch.float32)
             eng.numeric(self.A_local, self.B, IC_loc, JC, Cv)
             return IC_loc, JC[:nnz_loc], Cv[:nnz_loc]
-        # (1) segment sizes
-        offs = _segment_offsets(self.group, G, nnz_loc, IC_loc.device)
-        total = int(offs[G])
-        # (2) numeric straight into this rank's slice of the gathered arrays
-        rowPtr = eng.empty(self.m + 1, torch.int32)
-        JC = eng.empty(max(total, 1), torch.int32)
-        Cv = eng.empty(max(total, 1), torch.float32)
-        o0, o1 = int(offs[me]), int(offs[me + 1])
-        eng.numeric(self.A_local, self.B, IC_loc, JC[o0:o1] if o1 > o0 else JC[0:0], Cv[o0:o1] if o1 > o0 else Cv[0:0])
-        rowPtr[self.r0:self.r1] = IC_loc[:-1] + o0
-        if me == G - 1:
-            rowPtr[self.m] = total
-        # (3) allgatherv of the three arrays: pairwise send/recv, one link per peer
-        _allgatherv_csr(self.group, me, G, self.ends, self.m, offs, rowPtr, JC, Cv)
+        # (1) symbolic of every sub-block -> sizes of all (rank, sub-block) segments
+        ICs, sizes = [], []
+        for c in range(K):
+            ic, nz = eng.symbolic(self.A_sub[c], self.B, slot=c)
+            ICs.append(ic)
+            sizes.append(nz)
+        seg = _segment_sizes(self.group, G, sizes, ICs[0].device)          # [G, K] int64
+        offs = np.zeros(G * K + 1, dtype=np.int64)
+        np.cumsum(seg.reshape(-1), out=offs[1:])
+        total = int(offs[-1])
+        if total > 0x7fffffff:
+            raise hs.SpgemmError(f"nnz={total} does not fit the int32 CSR of the boundary")
+        rowPtr, JC, Cv = self._buffers(total)
+        # (2) numeric of sub-block c into its slice; (3) its send/recv pairs fly while sub-block c+1 computes
+        reqs = []
+        for c in range(K):
+            o0, o1 = int(offs[me * K + c]), int(offs[me * K + c + 1])
+            s0, s1 = int(self.sub_ends[me][c]), int(self.sub_ends[me][c + 1])
+            eng.numeric(self.A_sub[c], self.B, ICs[c], JC[o0:o1] if o1 > o0 else JC[0:0], Cv[o0:o1] if o1 > o0 else Cv[0:0], slot=c)
+            if s1 > s0:
+                rowPtr[s0:s1] = ICs[c][:-1] + o0
+            if me == G - 1 and c == K - 1:
+                rowPtr[self.m] = total
+            reqs += _exchange_block(self.group, me, G, K, c, self.sub_ends, self.m, offs, rowPtr, JC, Cv)
+        for req in reqs:
+            req.wait()
         return rowPtr, JC[:total], Cv[:total]
+
+    def _buffers(self, total):
+        b = self._buf
+        if b is None or b[1].numel() < max(total, 1):
+            cap = max(total + total // 16, 1)
+            b = (self.engine.empty(self.m + 1, torch.int32), self.engine.empty(cap, torch.int32),
+                 self.engine.empty(cap, torch.float32))
+            self._buf = b
+        return b
+
+
+def _exchange_block(group, me, G, K, c, sub_ends, m, offs, rowPtr, JC, Cv):
+    """Sub-block c of every rank: this rank sends its (rowPtr rows, colInd, values) segment to every peer and receives
+    theirs, as grouped isend/irecv pairs (one xGMI link per peer).  Returns the pending requests."""
+    ops = []
+    s0, s1 = int(sub_ends[me][c]), int(sub_ends[me][c + 1])
+    my_hi = s1 + (1 if (me == G - 1 and c == K - 1) else 0)
+    o0, o1 = int(offs[me * K + c]), int(offs[me * K + c + 1])
+    for r in range(G):
+        if r == me:
+            continue
+        a0, a1 = int(offs[r * K + c]), int(offs[r * K + c + 1])
+        rr0, rr1 = int(sub_ends[r][c]), int(sub_ends[r][c + 1]) + (1 if (r == G - 1 and c == K - 1) else 0)
+        if my_hi > s0:
+            ops.append(dist.P2POp(dist.isend, rowPtr[s0:my_hi], r, group))
+        if rr1 > rr0:
+            ops.append(dist.P2POp(dist.irecv, rowPtr[rr0:rr1], r, group))
+        if o1 > o0:
+            ops.append(dist.P2POp(dist.isend, JC[o0:o1], r, group))
+            ops.append(dist.P2POp(dist.isend, Cv[o0:o1], r, group))
+        if a1 > a0:
+            ops.append(dist.P2POp(dist.irecv, JC[a0:a1], r, group))
+            ops.append(dist.P2POp(dist.irecv, Cv[a0:a1], r, group))
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
+def _segment_sizes(group, G, sizes, device):
+    """all-gather of every rank's per-sub-block segment sizes -> int64 numpy [G, K]"""
+    K = len(sizes)
+    mine = torch.tensor(sizes, dtype=torch.int64, device=device)
+    out = [torch.zeros(K, dtype=torch.int64, device=device) for _ in range(G)]
+    dist.all_gather(out, mine, group=group)
+    return np.stack([x.cpu().numpy() for x in out]).astype(np.int64)
 
 
 def _allgatherv_csr(group, me, G, ends, m, offs, rowPtr, JC, Cv):

@@ -34,7 +34,7 @@ EXPORTS = [
     "spgemm_hip_memcpy_h2d", "spgemm_hip_memcpy_d2h", "spgemm_hip_memcpy_d2d", "hip_CSR_SpMM", "hip_gpuSpMM",
     "hip_gpuFlopsClassify", "hip_sgpuSpMM", "hip_csr_sort_rows", "spgemm_hip_selftest",
     "hip_spgemm_symbolic", "hip_spgemm_numeric", "hip_csr_row_flops", "spgemm_hip_kernel_name",
-    "hip_rmcl_prune", "hip_gpuRmclIter", "hip_coo_to_csr", "hip_flopsStats",
+    "hip_rmcl_prune", "hip_gpuRmclIter", "hip_coo_to_csr", "hip_flopsStats", "spgemm_hip_set_kernel_timing",
 ]
 
 
@@ -105,6 +105,7 @@ def lib():
                                       C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I]
         L.hip_csr_sort_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.spgemm_hip_selftest.argtypes = [C.c_void_p]
+        L.spgemm_hip_set_kernel_timing.argtypes = [C.c_void_p, C.c_uint]
         L.free = C.CDLL(None).free
         L.free.argtypes = [C.c_void_p]
         _lib = L
@@ -148,6 +149,10 @@ class Handle:
 
     def selftest(self):
         _check(lib().spgemm_hip_selftest(self._h), "spgemm_hip_selftest")
+
+    def set_kernel_timing(self, mask):
+        """bit i: bracket the launches of kernel i with HIP events (stats()['ms_kernel']); 0 = none (default)."""
+        _check(lib().spgemm_hip_set_kernel_timing(self._h, int(mask) & 0xFFFFFFFF), "spgemm_hip_set_kernel_timing")
 
     def close(self):
         if self._h:

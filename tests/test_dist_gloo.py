@@ -18,6 +18,10 @@ from sparse_matrix_with_flops_amd.dist import ShardedRMCL, ShardedSpGEMM, equal_
 class OracleEngine:
     """Same interface as dist.HipEngine, on CPU tensors, computing with oracle/ (test double)."""
 
+    def __init__(self, handles=1):
+        self.handles = [None] * handles           # one pending symbolic phase per slot, like HipEngine
+        self._C = [None] * handles
+
     def tensor(self, arr, dtype):
         return torch.from_numpy(np.ascontiguousarray(arr)).to(dtype)
 
@@ -34,13 +38,13 @@ class OracleEngine:
     def row_flops(self, A, B):
         return po.row_flops(self._host(A), self._host(B))
 
-    def symbolic(self, A, B):
-        self._C = po.omp_spmm(self._host(A), self._host(B))
-        return torch.from_numpy(self._C.rowPtr.copy()), self._C.nnz
+    def symbolic(self, A, B, slot=0):
+        self._C[slot] = po.omp_spmm(self._host(A), self._host(B))
+        return torch.from_numpy(self._C[slot].rowPtr.copy()), self._C[slot].nnz
 
-    def numeric(self, A, B, IC, JC_out, C_out):
-        JC_out.copy_(torch.from_numpy(self._C.colInd))
-        C_out.copy_(torch.from_numpy(self._C.values))
+    def numeric(self, A, B, IC, JC_out, C_out, slot=0):
+        JC_out.copy_(torch.from_numpy(self._C[slot].colInd))
+        C_out.copy_(torch.from_numpy(self._C[slot].values))
 
     def expand_prune(self, A, B):
         R = po.rmcl_iters(self._host(A), self._host(B), 1)               # prune(A*B), rows of A
@@ -55,25 +59,29 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, m, seed, q):
+def _worker(rank, world, port, m, seed, q, chunks=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         A = synth_csr(m, seed, 2)
-        job = ShardedSpGEMM(OracleEngine(), (A.rowPtr, A.colInd, A.values, A.rows, A.cols), None)
+        job = ShardedSpGEMM(OracleEngine(chunks), (A.rowPtr, A.colInd, A.values, A.rows, A.cols), None, chunks=chunks)
         rp, jc, cv = job.step()
+        rp, jc, cv = job.step()                      # second step: the gathered buffers are reused
+        assert job.chunks == chunks
         q.put((rank, rp.numpy().copy(), jc.numpy().copy(), cv.numpy().copy(), job.ends.copy(), job.local_flops))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_spgemm_gloo(world):
+@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 1), (2, 3), (3, 2)])
+def test_sharded_spgemm_gloo(world, chunks):
+    """chunks > 1: every rank's block is cut into sub-blocks whose send/recv pairs overlap the next sub-block's numeric
+    phase; the gathered C must not depend on the cut."""
     m, seed = 3000, 19
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, m, seed, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, m, seed, q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=240) for _ in range(world)]

@@ -30,16 +30,17 @@ def _graph(m, seed):
     return po.rmcl_init(A.rows, A.cols, A.colInd, ri, np.ones_like(A.values))
 
 
-def _worker(rank, world, port, kind, m, seed, q):
+def _worker(rank, world, port, kind, m, seed, q, chunks=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from sparse_matrix_with_flops_amd.dist import HipEngine, ShardedRMCL, ShardedSpGEMM
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        eng = HipEngine(0)
+        eng = HipEngine(0, handles=chunks)
         if kind == "spgemm":
             A = synth_csr(m, seed, 2)
-            job = ShardedSpGEMM(eng, (A.rowPtr, A.colInd, A.values, A.rows, A.cols), None)
+            job = ShardedSpGEMM(eng, (A.rowPtr, A.colInd, A.values, A.rows, A.cols), None, chunks=chunks)
             rp, jc, cv = job.step()
+            rp, jc, cv = job.step()                   # again: gathered buffers and handles are reused
             torch.cuda.synchronize()
             q.put((rank, rp.cpu().numpy(), jc.cpu().numpy(), cv.cpu().numpy(), job.ends.copy()))
         else:
@@ -53,27 +54,41 @@ def _worker(rank, world, port, kind, m, seed, q):
         dist.destroy_process_group()
 
 
-def _run(kind, m, seed, world=2):
+def _run(kind, m, seed, world=2, chunks=1):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, m, seed, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, m, seed, q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
-    outs = [q.get(timeout=300) for _ in range(world)]
+    outs = []
+    for _ in range(world):                            # a dead worker must fail the test at once, not after a long timeout
+        for _try in range(300):
+            try:
+                outs.append(q.get(timeout=1))
+                break
+            except Exception:
+                if any(p.exitcode not in (None, 0) for p in procs):
+                    raise AssertionError(f"a rank died: exit codes {[p.exitcode for p in procs]}")
+        else:
+            raise AssertionError("timeout waiting for the ranks")
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     return sorted(outs, key=lambda o: o[0])
 
 
-def test_sharded_spgemm_two_ranks_hip_engine():
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_sharded_spgemm_two_ranks_hip_engine(chunks):
+    """chunks = 3: the sub-block path (one handle per sub-block, exchange of block k overlapping numeric of k+1)."""
     m, seed = 40000, 19
-    outs = _run("spgemm", m, seed)
+    outs = _run("spgemm", m, seed, chunks=chunks)
     A = synth_csr(m, seed, 2)
     want = po.omp_spmm(A, A)
+    flops = po.row_flops(A, A)
+    prefix = np.concatenate([[0], np.cumsum(flops)]).astype(np.int64)
     for rank, rp, jc, cv, ends in outs:
-        assert 0 < ends[1] < m
+        assert np.array_equal(ends, po.equal_partition64(prefix, 2))                # arrayEqualPartition64 on device flops
         assert_parity(po.CSRHost(rp, jc, cv, m, m), want, what=f"rank {rank}")      # every rank holds the whole C
 
 
