@@ -78,6 +78,9 @@ int  spgemm_hip_set_kernel_timing(spgemm_handle* h, unsigned mask);
  *      CSR::toGpuCSR / toCpuCSR / deviceDispose  (nlibs/CSR.cc:342-379) ------------------------- */
 int  spgemm_hip_malloc(void** dptr, size_t bytes);
 int  spgemm_hip_free(void* dptr);
+/* bytes the caching allocator currently holds idle for `device` (tests; blocks are cached per device and given back
+ * to the driver when the last handle of the device is destroyed) */
+int  spgemm_hip_pool_cached_bytes(int device, size_t* bytes);
 int  spgemm_hip_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int  spgemm_hip_memcpy_d2h(void* dst, const void* src, size_t bytes);
 int  spgemm_hip_memcpy_d2d(void* dst, const void* src, size_t bytes);   /* device to device, same GPU */
@@ -170,6 +173,9 @@ int hip_sgpuSpMM(spgemm_handle* h,
  * the old ones). */
 int hip_rmcl_prune(spgemm_handle* h, int m, const int* dIC, const int* dJC, float* dC,
                    int** dIN, int** dJN, float** dCN, int* nnzN);
+/* the same with nnz(C) supplied by the caller (known on the host after every SpGEMM): saves one device read */
+int hip_rmcl_prune_n(spgemm_handle* h, int m, int nnz, const int* dIC, const int* dJC, const float* dC,
+                     int** dIN, int** dJN, float** dCN, int* nnzN);
 int hip_gpuRmclIter(int maxIter, int rows, int cols,
                     const int* gIA, const int* gJA, const float* gA, int gnnz,
                     const int* tIA, const int* tJA, const float* tA, int tnnz,

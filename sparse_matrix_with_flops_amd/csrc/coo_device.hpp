@@ -8,14 +8,82 @@
 //   CSR::toAbs                                      nlibs/CSR.h:152-158
 // i.e. what rmclInit (nlibs/qrmcl.cc:126-134) and the Matrix-Market/SNAP loaders do after parsing the text.
 //
-// The sort is a stable LSD radix sort (rocPRIM through hipCUB: a library sort is fine here, this is not the hot path)
-// of the 64-bit key row*cols+col carrying the entry's input position, over exactly the bits the shape needs.  Stable
-// order = input order inside a run of equal (row,col), so duplicates are summed left to right like the CPU loop
-// (bit-exact floats).  Included at the end of spgemm_hip.hip (uses its pool / error helpers).
+// The sort is our own stable LSD radix sort (8 bits per pass: per-block digit histograms in LDS, the library's scan
+// kernels over the digit-major histogram, ballot-ranked stable scatter) of the 64-bit key row*cols+col carrying the
+// entry's input position, over exactly the bits the shape needs.  Stable order = input order inside a run of equal
+// (row,col), so duplicates are summed left to right like the CPU loop (bit-exact floats; a run is summed by one lane,
+// which is what keeps the order -- a pair repeated very many times serialises that lane).
+// Included at the end of spgemm_hip.hip (uses its pool / error helpers and the k_scan_* kernels).
 #pragma once
-#include <hipcub/hipcub.hpp>
 
 namespace coo {
+
+constexpr int RS_THREADS = 256, RS_ITEMS = 8, RS_TILE = RS_THREADS * RS_ITEMS, RS_RADIX = 256;
+
+// pass 1 of a digit: how many keys of every digit value each block holds; blockHist is digit-major [256][nblk]
+__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(int n, const unsigned long long* __restrict__ keys, int shift,
+                                                           int nblk, int* __restrict__ blockHist) {
+  __shared__ int hist[RS_RADIX];
+  const int tid = threadIdx.x;
+  hist[tid] = 0;
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const long long idx = base + i * RS_THREADS + tid;
+    if (idx < n) atomicAdd(&hist[(int)((keys[idx] >> shift) & 255ull)], 1);
+  }
+  __syncthreads();
+  blockHist[(size_t)tid * nblk + blockIdx.x] = hist[tid];
+}
+
+// pass 2: stable scatter.  blockOff = exclusive scan of blockHist (digit-major, block-minor): where the block's keys
+// of each digit start.  Inside the block the order is (round, wave, lane) = index order: per round every wave ranks its
+// lanes among the lanes with the same digit (8 ballots), one thread per digit turns the per-wave counts into offsets.
+__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(int n, const unsigned long long* __restrict__ keysIn,
+                                                              const int* __restrict__ idxIn,
+                                                              unsigned long long* __restrict__ keysOut, int* __restrict__ idxOut,
+                                                              int shift, int nblk, const int* __restrict__ blockOff) {
+  constexpr int NWV = RS_THREADS / smf::WAVE;
+  __shared__ int wcnt[NWV][RS_RADIX];
+  __shared__ int woff[NWV][RS_RADIX];
+  __shared__ int run[RS_RADIX];
+  const int tid = threadIdx.x, w = tid >> 6;
+  run[tid] = blockOff[(size_t)tid * nblk + blockIdx.x];
+  const long long base = (long long)blockIdx.x * RS_TILE;
+  for (int i = 0; i < RS_ITEMS; ++i) {
+#pragma unroll
+    for (int q = 0; q < NWV; ++q) wcnt[q][tid] = 0;
+    __syncthreads();
+    const long long idx = base + i * RS_THREADS + tid;
+    const bool valid = idx < n;
+    unsigned long long key = 0ull;
+    int payload = 0;
+    if (valid) { key = keysIn[idx]; payload = idxIn[idx]; }
+    const int d = (int)((key >> shift) & 255ull);
+    unsigned long long peers = smf::ballot64(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long mb = smf::ballot64(valid && ((d >> b) & 1));
+      peers &= ((d >> b) & 1) ? mb : ~mb;
+    }
+    const int rank = smf::mask_rank(peers);
+    if (valid && rank == 0) wcnt[w][d] = __popcll(peers);
+    __syncthreads();
+    {
+      int r = run[tid];
+#pragma unroll
+      for (int q = 0; q < NWV; ++q) { woff[q][tid] = r; r += wcnt[q][tid]; }
+      run[tid] = r;
+    }
+    __syncthreads();
+    if (valid) {
+      const int dst = woff[w][d] + rank;
+      keysOut[dst] = key;
+      idxOut[dst] = payload;
+    }
+  }
+}
 
 __global__ void k_check_and_diag(int nnz, int rows, int cols, const int* __restrict__ ri, const int* __restrict__ ci,
                                  unsigned char* __restrict__ hasDiag, int* __restrict__ bad) {
@@ -68,7 +136,7 @@ __global__ void k_emit(int n, int nnzIn, int cols, const unsigned long long* __r
   const int o = pos[i];
   JA[o] = c;
   A[o] = useAbs ? fabsf(s) : s;
-  atomicAdd(&rowCnt[r + 1], 1);                  // integer counts: the result does not depend on the order
+  atomicAdd(&rowCnt[r], 1);                      // integer counts: the result does not depend on the order
 }
 
 __global__ void k_row_normalise(int rows, const int* __restrict__ IA, float* __restrict__ A) {
@@ -100,11 +168,12 @@ extern "C" int hip_coo_to_csr(spgemm_handle* h, int rows, int cols, int nnz, con
   int *bad = nullptr, *miss = nullptr, *missPos = nullptr, *idxA = nullptr, *idxB = nullptr, *head = nullptr, *pos = nullptr;
   unsigned long long *keyA = nullptr, *keyB = nullptr;
   void* tmp = nullptr;
+  int* bhist = nullptr;                          // digit-major per-block histograms / offsets of the radix passes
   int *IA = nullptr, *JA = nullptr;
   float* A = nullptr;
   auto cleanup = [&](int rc) {
     for (void* p : {(void*)hasDiag, (void*)bad, (void*)miss, (void*)missPos, (void*)idxA, (void*)idxB, (void*)head,
-                    (void*)pos, (void*)keyA, (void*)keyB, tmp})
+                    (void*)pos, (void*)keyA, (void*)keyB, tmp, (void*)bhist})
       pool().release(p);
     if (rc != SPGEMM_OK) { pool().release(IA); pool().release(JA); pool().release(A); }
     return rc;
@@ -113,14 +182,26 @@ extern "C" int hip_coo_to_csr(spgemm_handle* h, int rows, int cols, int nnz, con
 #define COO_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return cleanup(fail(SPGEMM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
   const int T = 256;
   auto grid = [&](long long n) { return dim3((unsigned)std::max<long long>(1, (n + T - 1) / T)); };
-  size_t tmpBytes = 0, need = 0;
-  hipcub::DeviceScan::ExclusiveSum(nullptr, need, (int*)nullptr, (int*)nullptr, (int)std::max<long long>(maxTotal, (long long)rows + 1));
-  tmpBytes = need;
   const int keyBits = std::max(1, 64 - __builtin_clzll((unsigned long long)std::max(1, rows) * (unsigned long long)std::max(1, cols)));
-  hipcub::DeviceRadixSort::SortPairs(nullptr, need, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr,
-                                     (int*)nullptr, (int)std::max<long long>(maxTotal, 1), 0, keyBits);
-  tmpBytes = std::max(tmpBytes, need);
-  COO_ALLOC(tmp, tmpBytes);
+  // scratch of the scans: tile sums of the longest array scanned below (entries, rows + 1, or 256 x radix blocks)
+  const long long nblkMax = (maxTotal + coo::RS_TILE - 1) / coo::RS_TILE + 1;
+  const long long longest = std::max<long long>(std::max<long long>(maxTotal, (long long)rows + 1), nblkMax * coo::RS_RADIX) + 1;
+  unsigned long long* tile = nullptr;
+  COO_ALLOC(tmp, sizeof(unsigned long long) * (size_t)((longest + SCAN_TILE - 1) / SCAN_TILE + 2));
+  tile = (unsigned long long*)tmp;
+  // in-place exclusive scan of data[0..cnt) with data[cnt] = total (k_scan_* of the SpGEMM path), 64-bit total on the host
+  auto scan_inplace = [&](int* data, int cnt, unsigned long long* hostTotal) -> hipError_t {
+    const int ntiles = std::max(1, cdiv(cnt, SCAN_TILE));
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(SCAN_THREADS), 0, s, cnt, data, tile + 1);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, ntiles, tile + 1, tile);
+    hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(SCAN_THREADS), 0, s, cnt, data, tile + 1, tile, 1);
+    if (hostTotal) {
+      hipError_t e = hipMemcpyAsync(hostTotal, tile, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+      if (e != hipSuccess) return e;
+      return hipStreamSynchronize(s);
+    }
+    return hipGetLastError();
+  };
   COO_ALLOC(bad, sizeof(int));
   COO_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
   // (1) validation, diagonal flags, self loops to append
@@ -128,19 +209,16 @@ extern "C" int hip_coo_to_csr(spgemm_handle* h, int rows, int cols, int nnz, con
   if (loops && rows > 0) {
     COO_ALLOC(hasDiag, (size_t)rows);
     COO_ALLOC(miss, sizeof(int) * (size_t)rows);
-    COO_ALLOC(missPos, sizeof(int) * (size_t)rows);
+    COO_ALLOC(missPos, sizeof(int) * ((size_t)rows + 1));
     COO_HIP(hipMemsetAsync(hasDiag, 0, (size_t)rows, s));
   }
   if (nnz > 0) hipLaunchKernelGGL(coo::k_check_and_diag, grid(nnz), dim3(T), 0, s, nnz, rows, cols, dRow, dCol, hasDiag, bad);
   if (loops && rows > 0) {
     hipLaunchKernelGGL(coo::k_missing_flags, grid(rows), dim3(T), 0, s, rows, hasDiag, miss);
-    need = tmpBytes;
-    COO_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, need, miss, missPos, rows, s));
-    int lastFlag = 0, lastPos = 0;
-    COO_HIP(hipMemcpyAsync(&lastFlag, miss + rows - 1, sizeof(int), hipMemcpyDeviceToHost, s));
-    COO_HIP(hipMemcpyAsync(&lastPos, missPos + rows - 1, sizeof(int), hipMemcpyDeviceToHost, s));
-    COO_HIP(hipStreamSynchronize(s));
-    extra = lastPos + lastFlag;
+    COO_HIP(hipMemcpyAsync(missPos, miss, sizeof(int) * (size_t)rows, hipMemcpyDeviceToDevice, s));
+    unsigned long long nmiss = 0;
+    COO_HIP(scan_inplace(missPos, rows, &nmiss));
+    extra = (int)nmiss;
   }
   int hbad = 0;
   COO_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -163,26 +241,34 @@ extern "C" int hip_coo_to_csr(spgemm_handle* h, int rows, int cols, int nnz, con
   COO_ALLOC(idxB, sizeof(int) * (size_t)total);
   hipLaunchKernelGGL(coo::k_make_keys, grid(std::max(nnz, loops ? rows : 0)), dim3(T), 0, s, nnz, rows, cols, dRow, dCol,
                      missPos, loops ? miss : (int*)nullptr, keyA, idxA, total);
-  need = tmpBytes;
-  COO_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, need, keyA, keyB, idxA, idxB, total, 0, keyBits, s));
+  {
+    const int nblk = cdiv(total, coo::RS_TILE);
+    COO_ALLOC(bhist, sizeof(int) * ((size_t)nblk * coo::RS_RADIX + 1));
+    for (int shift = 0; shift < keyBits; shift += 8) {     // stable LSD passes over exactly the bits the shape needs
+      hipLaunchKernelGGL(coo::k_radix_hist, dim3(nblk), dim3(coo::RS_THREADS), 0, s, total, keyA, shift, nblk, bhist);
+      COO_HIP(scan_inplace(bhist, nblk * coo::RS_RADIX, nullptr));
+      hipLaunchKernelGGL(coo::k_radix_scatter, dim3(nblk), dim3(coo::RS_THREADS), 0, s, total, keyA, idxA, keyB, idxB, shift,
+                         nblk, bhist);
+      std::swap(keyA, keyB);
+      std::swap(idxA, idxB);
+    }
+    std::swap(keyA, keyB);                                 // the sorted arrays are called keyB / idxB below
+    std::swap(idxA, idxB);
+  }
   // (3) heads of runs -> output positions
   COO_ALLOC(head, sizeof(int) * (size_t)total);
-  COO_ALLOC(pos, sizeof(int) * (size_t)total);
-  hipLaunchKernelGGL(coo::k_heads, grid(total), dim3(T), 0, s, total, keyB, dedupe, head);
-  need = tmpBytes;
-  COO_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, need, head, pos, total, s));
-  int lastHead = 0, lastPos = 0;
-  COO_HIP(hipMemcpyAsync(&lastHead, head + total - 1, sizeof(int), hipMemcpyDeviceToHost, s));
-  COO_HIP(hipMemcpyAsync(&lastPos, pos + total - 1, sizeof(int), hipMemcpyDeviceToHost, s));
-  COO_HIP(hipStreamSynchronize(s));
-  const int outN = lastPos + lastHead;
+  COO_ALLOC(pos, sizeof(int) * ((size_t)total + 1));
+  hipLaunchKernelGGL(coo::k_heads, grid(total), dim3(T), 0, s, total, keyB, dedupe, pos);
+  COO_HIP(hipMemcpyAsync(head, pos, sizeof(int) * (size_t)total, hipMemcpyDeviceToDevice, s));
+  unsigned long long nheads = 0;
+  COO_HIP(scan_inplace(pos, total, &nheads));
+  const int outN = (int)nheads;
   // (4) emit columns / values / row counts, scan the counts, optional row normalisation
   COO_ALLOC(JA, sizeof(int) * (size_t)std::max(outN, 1));
   COO_ALLOC(A, sizeof(float) * (size_t)std::max(outN, 1));
   hipLaunchKernelGGL(coo::k_emit, grid(total), dim3(T), 0, s, total, nnz, cols, keyB, idxB, head, pos, dVal, dedupe,
                      (flags & SPGEMM_COO_ABS) ? 1 : 0, JA, A, IA);
-  need = tmpBytes;
-  COO_HIP(hipcub::DeviceScan::InclusiveSum(tmp, need, IA, IA, rows + 1, s));
+  COO_HIP(scan_inplace(IA, rows, nullptr));               // counts -> rowPtr, IA[rows] = nnz
   if ((flags & SPGEMM_COO_ROW_NORMALISE) && rows > 0)
     hipLaunchKernelGGL(coo::k_row_normalise, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, rows, IA, A);
   COO_HIP(hipGetLastError());

@@ -145,6 +145,11 @@ __device__ __forceinline__ int next_pow2_clamped(int x, int lo, int hi) {
 
 __device__ __forceinline__ int log2_pow2(int p) { return 31 - __clz(p); }
 
+// power-of-two table for `items` distinct keys at load <= 1/2, clamped to [lo, hi]; `items` may be INT_MAX (saturated flops)
+__device__ __forceinline__ int table_size(int items, int lo, int hi) {
+  return items >= hi / 2 ? hi : next_pow2_clamped(2 * items, lo, hi);
+}
+
 // ------------------------------------------------------------------------------------------------
 // LDS open-addressing hash (keys >= 0, EMPTY_KEY = -1), multiplicative hash, linear probing.
 // hash_insert: one key per lane (small-row kernels).  Returns the slot of `c`; *is_new is set when this call
@@ -566,7 +571,7 @@ __global__ __launch_bounds__(256) void k_sym_small(const int* __restrict__ binPt
     const bool live = q < count;
     const int row = live ? rowIds[first + q] : 0;
     const int F = live ? rowFlops[row] : 1;
-    const int size = next_pow2_clamped(2 * F, 8, TBL);
+    const int size = table_size(F, 8, TBL);
     const int shift = 32 - log2_pow2(size);
     for (int i = gl; i < size; i += G) keys[g][i] = EMPTY_KEY;
     wave_lds_sync();
@@ -614,7 +619,7 @@ __global__ __launch_bounds__(256) void k_num_small(const int* __restrict__ binPt
     const bool live = q < count;
     const int row = live ? rowIds[first + q] : 0;
     const int F = live ? rowFlops[row] : 1;
-    const int size = next_pow2_clamped(2 * F, 8, TBL);
+    const int size = table_size(F, 8, TBL);
     const int shift = 32 - log2_pow2(size);
     for (int i = gl; i < size; i += G) tab[g][i] = EMPTY_SLOT;
     wave_lds_sync();
@@ -736,7 +741,7 @@ __global__ __launch_bounds__(256) void k_sym_g16(const int* __restrict__ binPtr,
     const bool live = q < count;
     const int row = live ? rowIds[first + q] : 0;
     const int F = live ? rowFlops[row] : 1;
-    const int size = next_pow2_clamped(2 * F, 16, TBL);
+    const int size = table_size(F, 16, TBL);
     const int shift = 32 - log2_pow2(size);
     for (int i = gl; i < size; i += 16) keys[g][i] = EMPTY_KEY;
     wave_lds_sync();
@@ -779,7 +784,7 @@ __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr,
     const int row = live ? rowIds[first + q] : 0;
     const int off = live ? IC[row] : 0;
     const int want = live ? IC[row + 1] - off : 0;
-    const int size = next_pow2_clamped(2 * want, 16, TBL);
+    const int size = table_size(want, 16, TBL);
     const int shift = 32 - log2_pow2(size);
     for (int i = gl; i < size; i += 16) tab[g][i] = EMPTY_SLOT;
     wave_lds_sync();
@@ -1143,7 +1148,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ 
       qn = next_row<QB>(qctr, &qslot, q);
       nxt = load_meta_sym(rows, qn, count, IA, rowFlops);
     }
-    const int size = next_pow2_clamped(2 * cur.x0, 64, TBL);
+    const int size = table_size(cur.x0, 64, TBL);
     const int shift = 32 - log2_pow2(size);
     clear_table(keys, nullptr, size, tid, WAVE * NW);
     if (tid == 0) cnt_s = 0;
@@ -1211,7 +1216,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
     }
     const int off = cur.x0;
     const int want = cur.x1 - off;                      // exact distinct count from the symbolic pass
-    const int size = next_pow2_clamped(2 * want, T > 64 ? T : 64, TBL);
+    const int size = table_size(want, T > 64 ? T : 64, TBL);
     const int shift = 32 - log2_pow2(size);
     clear_slots(tab, size, tid, T);
     if (NW > 1 && tid == 0) emitted = 0;
@@ -1653,9 +1658,12 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int ntiles, unsigned long l
   if (tid == 0) *total = running;
 }
 
+// clampTotal: IC[m] = min(total, INT_MAX) (C.rowPtr: the host rejects an overflow anyway); otherwise the total wraps
+// modulo 2^32 like the interior prefixes, so that differences of neighbours stay exact (the dflops scan of the
+// classification API, whose consumers take differences)
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(int m, int* __restrict__ IC,
                                                               const unsigned long long* __restrict__ tileOff,
-                                                              const unsigned long long* __restrict__ total) {
+                                                              const unsigned long long* __restrict__ total, int clampTotal) {
   __shared__ int wsum[16];
   const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
   const int base = blockIdx.x * SCAN_TILE + tid * SCAN_ITEMS;
@@ -1673,7 +1681,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(int m, int* __restr
   for (int i = 0; i < SCAN_ITEMS; ++i) { if (base + i < m) IC[base + i] = run; run += v[i]; }
   if (blockIdx.x == 0 && tid == 0) {
     const unsigned long long t = *total;
-    IC[m] = t > 0x7fffffffULL ? 0x7fffffff : (int)t;
+    IC[m] = (clampTotal && t > 0x7fffffffULL) ? 0x7fffffff : (int)(unsigned)t;
   }
 }
 
@@ -1687,12 +1695,15 @@ __global__ void k_gather_flops(int m, const int* __restrict__ rowIds, const int*
   if (q < m) out[q] = rowFlops[rowIds[q]];
 }
 
-// CSR::makeOrdered on the device (nlibs/CSR.cc:73-86): one block per row, bitonic sort in LDS for rows
-// of <= SORT_MAX entries.  Longer rows are checked and, if unsorted, sorted by odd-even transposition in
-// global memory (slow, correct).  Used by tests/drivers, not by the timed path.
+// CSR::makeOrdered on the device (nlibs/CSR.cc:73-86).  Rows of <= SORT_MAX entries: one block per row, bitonic sort in
+// LDS (k_sort_rows, which also counts the longer rows that are not sorted yet).  Longer rows (the output of the big-row
+// hash kernel: up to tens of thousands of entries): a per-row stable LSD radix sort over the column bits, 8 bits per
+// pass, between the row's own segment of the arrays and of a scratch copy (k_sort_long_rows) -- the reference's device
+// primitives for this are nlibs/bitonic_sort.cuh:19-87 and mindex2-cuda/radix_sort.cuh:2-62.
+// Used by tests/drivers, not by the timed path.
 constexpr int SORT_MAX = 4096;
 __global__ __launch_bounds__(256) void k_sort_rows(int m, const int* __restrict__ IC, int* __restrict__ JC,
-                                                    float* __restrict__ C) {
+                                                    float* __restrict__ C, int* __restrict__ longUnsorted) {
   __shared__ int sk[SORT_MAX];
   __shared__ float sv[SORT_MAX];
   __shared__ int unsorted;
@@ -1727,18 +1738,91 @@ __global__ __launch_bounds__(256) void k_sort_rows(int m, const int* __restrict_
       for (int i = tid; i + 1 < len; i += 256) bad |= JC[s + i] > JC[s + i + 1];
       if (bad) atomicOr(&unsorted, 1);
       __syncthreads();
-      const bool need = unsorted != 0;
+      if (tid == 0 && unsorted) atomicAdd(longUnsorted, 1);
       __syncthreads();
-      if (!need) continue;
-      for (int phase = 0; phase < len; ++phase) {
-        for (int i = (phase & 1) + 2 * tid; i + 1 < len; i += 512) {
-          const int a = JC[s + i], b = JC[s + i + 1];
-          if (a > b) { JC[s + i] = b; JC[s + i + 1] = a; const float t = C[s + i]; C[s + i] = C[s + i + 1]; C[s + i + 1] = t; }
-        }
-        __threadfence();
-        __syncthreads();
-      }
     }
+  }
+}
+
+// rows longer than SORT_MAX that are not sorted: stable LSD radix sort, 8 bits per pass over `keyBits` column bits,
+// ping-pong between (JC, C) and (JS, CS) inside the row's own segment [IC[row], IC[row+1]); an odd number of passes
+// ends with a copy back.  Block = 256 threads; a pass = histogram of the row, scan of the 256 counts, then rounds of
+// 256 elements ranked with ballots (order inside the block = index order, so every pass is stable).
+__global__ __launch_bounds__(256) void k_sort_long_rows(int m, const int* __restrict__ IC, int* __restrict__ JC,
+                                                         float* __restrict__ C, int* __restrict__ JS, float* __restrict__ CS,
+                                                         int keyBits) {
+  constexpr int NWV = 4;
+  __shared__ int hist[256];
+  __shared__ int run[256];
+  __shared__ int wcnt[NWV][256];
+  __shared__ int woff[NWV][256];
+  __shared__ int unsorted;
+  const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+  for (int row = blockIdx.x; row < m; row += gridDim.x) {
+    const int s = IC[row], len = IC[row + 1] - s;
+    if (len <= SORT_MAX) continue;                       // block-uniform
+    if (tid == 0) unsorted = 0;
+    __syncthreads();
+    int bad = 0;
+    for (int i = tid; i + 1 < len; i += 256) bad |= JC[s + i] > JC[s + i + 1];
+    if (bad) atomicOr(&unsorted, 1);
+    __syncthreads();
+    const bool need = unsorted != 0;
+    __syncthreads();
+    if (!need) continue;
+    int* kin = JC + s; float* vin = C + s;
+    int* kout = JS + s; float* vout = CS + s;
+    int passes = 0;
+    for (int shift = 0; shift < keyBits; shift += 8, ++passes) {
+      hist[tid] = 0;
+      __syncthreads();
+      for (int i = tid; i < len; i += 256) atomicAdd(&hist[(kin[i] >> shift) & 255], 1);
+      __syncthreads();
+      if (w == 0) {                                      // exclusive scan of the 256 counts by one wave, 4 per lane
+        int c[4], t = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { c[q] = hist[lane * 4 + q]; t += c[q]; }
+        int ex = wave_incl_add(t) - t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { run[lane * 4 + q] = ex; ex += c[q]; }
+      }
+      __syncthreads();
+      for (int i0 = 0; i0 < len; i0 += 256) {
+#pragma unroll
+        for (int q = 0; q < NWV; ++q) wcnt[q][tid] = 0;
+        __syncthreads();
+        const int i = i0 + tid;
+        const bool valid = i < len;
+        const int key = valid ? kin[i] : 0;
+        const float val = valid ? vin[i] : 0.f;
+        const int d = (key >> shift) & 255;
+        unsigned long long peers = ballot64(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const unsigned long long mb = ballot64(valid && ((d >> b) & 1));
+          peers &= ((d >> b) & 1) ? mb : ~mb;
+        }
+        const int rank = mask_rank(peers);
+        if (valid && rank == 0) wcnt[w][d] = __popcll(peers);
+        __syncthreads();
+        {
+          int r = run[tid];
+#pragma unroll
+          for (int q = 0; q < NWV; ++q) { woff[q][tid] = r; r += wcnt[q][tid]; }
+          run[tid] = r;
+        }
+        __syncthreads();
+        if (valid) { const int dst = woff[w][d] + rank; kout[dst] = key; vout[dst] = val; }
+      }
+      __threadfence_block();
+      __syncthreads();
+      int* tk = kin; kin = kout; kout = tk;
+      float* tv = vin; vin = vout; vout = tv;
+    }
+    if (passes & 1) {                                    // the sorted row sits in the scratch segment
+      for (int i = tid; i < len; i += 256) { kout[i] = kin[i]; vout[i] = vin[i]; }
+    }
+    __syncthreads();
   }
 }
 

@@ -52,12 +52,21 @@ extern "C" const char* spgemm_hip_last_error(void) { return g_err; }
 // so the per-call allocation of C costs a map lookup in steady state instead of a hipMalloc.
 // ------------------------------------------------------------------------------------------------
 namespace {
+// Blocks are cached PER DEVICE: a block freed on device 0 is never handed to an allocation made for device 1.
+// INVARIANT the reuse relies on: every entry point of this library returns only after the work it queued has completed
+// (hipStreamSynchronize on the handle's stream before the function returns), so a block that comes back through
+// spgemm_hip_free / release() is idle; callers that queue their own work on such a block must finish it before freeing
+// (the same rule cudaFree imposes implicitly by synchronising).  SPGEMM_POOL_CHECK=1 makes release() synchronise the
+// device first (debugging aid for foreign streams).
 struct DevPool {
+  struct Blk { size_t size; int dev; };
   std::mutex mu;
-  std::map<void*, size_t> live;                 // ptr -> rounded size
-  std::multimap<size_t, void*> free_blocks;     // rounded size -> ptr
+  std::map<void*, Blk> live;                                   // ptr -> rounded size, owning device
+  std::map<int, std::multimap<size_t, void*>> free_blocks;     // device -> rounded size -> ptr
   size_t cached_bytes = 0;
+  bool check = false;
   static constexpr size_t kMaxCached = size_t(64) << 30;   // 64 GiB of 288 GiB HBM
+  DevPool() { const char* e = getenv("SPGEMM_POOL_CHECK"); check = e && e[0] == '1'; }
   static size_t round_up(size_t b) {
     if (b < 512) b = 512;
     if (b <= (size_t(1) << 20)) return (b + 511) & ~size_t(511);
@@ -66,49 +75,60 @@ struct DevPool {
   }
   hipError_t alloc(void** p, size_t bytes) {
     const size_t r = round_up(bytes);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     {
       std::lock_guard<std::mutex> lk(mu);
-      auto it = free_blocks.lower_bound(r);
+      auto& fb = free_blocks[dev];
+      auto it = fb.lower_bound(r);
       // best fit, and a cached block up to 4x the request is still better than a hipMalloc (tens of ms for GB-sized
       // blocks; 288 GB of HBM make the slack affordable): R-MCL shrinks its matrices from one iteration to the next
-      if (it != free_blocks.end() && it->first <= 4 * r + (size_t(2) << 20)) {
+      if (it != fb.end() && it->first <= 4 * r + (size_t(2) << 20)) {
         *p = it->second;
-        live[*p] = it->first;
+        live[*p] = Blk{it->first, dev};
         cached_bytes -= it->first;
-        free_blocks.erase(it);
+        fb.erase(it);
         return hipSuccess;
       }
     }
     hipError_t e = hipMalloc(p, r);
     if (e != hipSuccess) {                       // give cached memory back and retry once
-      trim();
+      trim(dev);
       e = hipMalloc(p, r);
     }
-    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu); live[*p] = r; }
+    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu); live[*p] = Blk{r, dev}; }
     return e;
   }
   hipError_t release(void* p) {
     if (!p) return hipSuccess;
-    size_t sz = 0;
+    if (check) (void)hipDeviceSynchronize();
+    Blk blk{0, 0};
     {
       std::lock_guard<std::mutex> lk(mu);
       auto it = live.find(p);
       if (it == live.end()) return hipFree(p);   // not ours: plain hipFree
-      sz = it->second;
+      blk = it->second;
       live.erase(it);
-      if (cached_bytes + sz <= kMaxCached) {
-        free_blocks.emplace(sz, p);
-        cached_bytes += sz;
+      if (cached_bytes + blk.size <= kMaxCached) {
+        free_blocks[blk.dev].emplace(blk.size, p);
+        cached_bytes += blk.size;
         return hipSuccess;
       }
     }
     return hipFree(p);
   }
-  void trim() {
+  // give the cached (idle) blocks of one device back to the driver
+  void trim(int dev) {
     std::lock_guard<std::mutex> lk(mu);
-    for (auto& kv : free_blocks) (void)hipFree(kv.second);
-    free_blocks.clear();
-    cached_bytes = 0;
+    auto& fb = free_blocks[dev];
+    for (auto& kv : fb) { cached_bytes -= kv.first; (void)hipFree(kv.second); }
+    fb.clear();
+  }
+  size_t cached_on(int dev) {
+    std::lock_guard<std::mutex> lk(mu);
+    size_t t = 0;
+    for (auto& kv : free_blocks[dev]) t += kv.first;
+    return t;
   }
 };
 DevPool& pool() { static DevPool* p = new DevPool(); return *p; }
@@ -172,6 +192,9 @@ struct spgemm_handle {
   int h1sym = 32;                    // blocks per CU of the wave-per-row symbolic kernel (SPGEMM_H1SYM, experiments)
   spgemm_stats stats;
 };
+
+static std::mutex g_count_mu;
+static std::map<int, int> g_handles_on;          // device -> live handles (the pool is trimmed when the last one goes)
 
 static int ws_free(spgemm_handle* h) {
   hipFree(h->rowFlops); hipFree(h->binId); hipFree(h->blockHist); hipFree(h->blockOff);
@@ -254,6 +277,7 @@ extern "C" int spgemm_hip_create(spgemm_handle** out, int device) {
   HIPCHK(hipEventCreateWithFlags(&h->evMid, hipEventDisableTiming));
   { const char* e = getenv("SPGEMM_KTIMING"); if (e) h->ktiming = (unsigned)strtoul(e, nullptr, 0); }
   memset(&h->stats, 0, sizeof(h->stats));
+  { std::lock_guard<std::mutex> lk(g_count_mu); ++g_handles_on[device]; }
   // the big-row kernels use more than the default 64 KB of dynamic LDS
   HIPCHK(hipFuncSetAttribute((const void*)k_sym_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigSymShared)));
   HIPCHK(hipFuncSetAttribute((const void*)k_num_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigNumShared)));
@@ -280,6 +304,9 @@ extern "C" int spgemm_hip_destroy(spgemm_handle* h) {
   if (h->fork_ev) hipEventDestroy(h->fork_ev);
   for (auto& e : h->join_ev) if (e) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
+  bool last = false;
+  { std::lock_guard<std::mutex> lk(g_count_mu); last = --g_handles_on[h->device] <= 0; }
+  if (last) pool().trim(h->device);              // cached blocks are idle by the pool's invariant
   delete h;
   return SPGEMM_OK;
 }
@@ -311,6 +338,11 @@ extern "C" int spgemm_hip_malloc(void** dptr, size_t bytes) {
   if (!dptr) return fail(SPGEMM_ERR_ARG, "dptr is null");
   *dptr = nullptr;
   HIPCHK(pool().alloc(dptr, bytes ? bytes : 1));
+  return SPGEMM_OK;
+}
+extern "C" int spgemm_hip_pool_cached_bytes(int device, size_t* bytes) {
+  if (!bytes) return fail(SPGEMM_ERR_ARG, "bytes is null");
+  *bytes = pool().cached_on(device);
   return SPGEMM_OK;
 }
 extern "C" int spgemm_hip_free(void* dptr) {
@@ -454,12 +486,12 @@ static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJB,
 }
 
 // exclusive scan of cnt[0..m) in place, cnt[m] = total; 64-bit total lands in *dTotal
-static int launch_scan(spgemm_handle* h, int* cnt, int m, unsigned long long* dTotal) {
+static int launch_scan(spgemm_handle* h, int* cnt, int m, unsigned long long* dTotal, bool clampTotal = true) {
   const int ntiles = std::max(1, cdiv(m, SCAN_TILE));
   KTimer t(h, SPGEMM_K_SCAN);
   hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(SCAN_THREADS), 0, h->stream, m, cnt, h->tileSum);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, h->stream, ntiles, h->tileSum, dTotal);
-  hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(SCAN_THREADS), 0, h->stream, m, cnt, h->tileSum, dTotal);
+  hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(SCAN_THREADS), 0, h->stream, m, cnt, h->tileSum, dTotal, clampTotal ? 1 : 0);
   HIPCHK(hipGetLastError());
   return SPGEMM_OK;
 }
@@ -753,6 +785,7 @@ extern "C" int hip_csr_row_flops(spgemm_handle* h, const int* dIA, const int* dJ
   if (!h) CHK(default_handle(&h));
   if (m < 0 || !dIA || (m > 0 && !dRowFlops)) return fail(SPGEMM_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(h->device));
+  h->sym_m = -1;                                   // the classification workspace is about to be overwritten
   CHK(ws_ensure(h, m));
   int* tmpIC = nullptr;
   HIPCHK(pool().alloc((void**)&tmpIC, sizeof(int) * ((size_t)m + 1)));
@@ -800,6 +833,7 @@ extern "C" int hip_gpuFlopsClassify(spgemm_handle* h, const int* dIA, const int*
   if (!dIA) return fail(SPGEMM_ERR_ARG, "A.rowPtr is null");
   if (!h) CHK(default_handle(&h));
   HIPCHK(hipSetDevice(h->device));
+  h->sym_m = -1;
   CHK(ws_ensure(h, m));
   int *ids = nullptr, *fl = nullptr, *tmpIC = nullptr;
   auto cleanup = [&](int rc) { pool().release(ids); pool().release(fl); pool().release(tmpIC); return rc; };
@@ -813,7 +847,7 @@ extern "C" int hip_gpuFlopsClassify(spgemm_handle* h, const int* dIA, const int*
   if (m > 0) {
     hipMemcpyAsync(ids, h->rowIds, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, s);
     hipLaunchKernelGGL(k_gather_flops, dim3(cdiv(m, 256)), dim3(256), 0, s, m, h->rowIds, h->rowFlops, fl);
-    if ((rc = launch_scan(h, fl, m, &h->dsmall->nnzC64))) return cleanup(rc);
+    if ((rc = launch_scan(h, fl, m, &h->dsmall->nnzC64, false))) return cleanup(rc);   // wraps: differences stay exact
   } else {
     hipMemsetAsync(fl, 0, sizeof(int), s);
   }
@@ -957,29 +991,35 @@ extern "C" int hip_CSR_SpMM(const int* IA, const int* JA, const float* A, int nn
 // ------------------------------------------------------------------------------------------------
 // R-MCL
 // ------------------------------------------------------------------------------------------------
-extern "C" int hip_rmcl_prune(spgemm_handle* h, int m, const int* dIC, const int* dJC, float* dC, int** dIN, int** dJN,
-                              float** dCN, int* nnzN) {
+// nnzIn >= 0: the caller knows nnz(C) (it is on the host after every SpGEMM of this library) and the choice of lanes per
+// row needs no device read; nnzIn < 0: one 4-byte copy fetches it.
+static int rmcl_prune_impl(spgemm_handle* h, int m, long long nnzIn, const int* dIC, const int* dJC, const float* dC,
+                           int** dIN, int** dJN, float** dCN, int* nnzN) {
   if (!dIN || !dJN || !dCN || !nnzN) return fail(SPGEMM_ERR_ARG, "output pointer is null");
   *dIN = nullptr; *dJN = nullptr; *dCN = nullptr; *nnzN = 0;
   if (m < 0 || !dIC) return fail(SPGEMM_ERR_ARG, "bad argument");
   if (!h) CHK(default_handle(&h));
   HIPCHK(hipSetDevice(h->device));
+  h->sym_m = -1;                                   // scan scratch and the small device block are shared with a pending phase
   CHK(ws_ensure(h, m));
   int* newPtr = nullptr; int* JN = nullptr; float* CN = nullptr; float* th = nullptr; float* ks = nullptr;
   auto cleanup = [&](int rc) { pool().release(newPtr); pool().release(JN); pool().release(CN); pool().release(th); pool().release(ks); return rc; };
+  auto hipfail = [&](const char* what) { return cleanup(fail(SPGEMM_ERR_HIP, "rmcl prune: %s: %s", what, hipGetErrorString(hipGetLastError()))); };
   if (hipSuccess != pool().alloc((void**)&newPtr, sizeof(int) * ((size_t)m + 1)) ||
       hipSuccess != pool().alloc((void**)&th, sizeof(float) * (size_t)std::max(m, 1)) ||
       hipSuccess != pool().alloc((void**)&ks, sizeof(float) * (size_t)std::max(m, 1)))
-    return cleanup(fail(SPGEMM_ERR_HIP, "device allocation failed"));
+    return hipfail("device allocation failed");
   hipStream_t s = h->stream;
-  HIPCHK(hipMemsetAsync(&h->dsmall->nnzC64, 0, sizeof(unsigned long long), s));
-  // lanes per row: 16 for short rows; a whole wave once rows average ~100 entries (needs nnz: one small copy)
-  int nnzIn = 0;
-  if (m > 0) {
-    HIPCHK(hipMemcpyAsync(&nnzIn, dIC + m, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+  if (hipMemsetAsync(&h->dsmall->nnzC64, 0, sizeof(unsigned long long), s) != hipSuccess) return hipfail("memset");
+  // lanes per row: 16 for short rows; a whole wave once rows average ~100 entries
+  if (m > 0 && nnzIn < 0) {
+    int tmp = 0;
+    if (hipMemcpyAsync(&tmp, dIC + m, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+      return hipfail("reading nnz");
+    nnzIn = tmp;
   }
-  const bool wide = m > 0 && (long long)nnzIn >= 96ll * m;
+  const bool wide = m > 0 && nnzIn >= 96ll * m;
   const int grid = wide ? clampi(cdiv(m, 4), 1, h->numCU * 32) : clampi(cdiv(m, 16), 1, h->numCU * 16);
   if (m > 0) {
     if (wide) hipLaunchKernelGGL(k_rmcl_stats<64>, dim3(grid), dim3(256), 0, s, m, dIC, dC, newPtr, th, ks);
@@ -991,20 +1031,31 @@ extern "C" int hip_rmcl_prune(spgemm_handle* h, int m, const int* dIC, const int
   }
   if (hipMemcpyAsync(&h->hsmall->nnzC64, &h->dsmall->nnzC64, sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
       hipStreamSynchronize(s) != hipSuccess)
-    return cleanup(fail(SPGEMM_ERR_HIP, "rmcl prune failed: %s", hipGetErrorString(hipGetLastError())));
+    return hipfail("kept-entry count");
   const int nz = (int)h->hsmall->nnzC64;
   if (hipSuccess != pool().alloc((void**)&JN, sizeof(int) * (size_t)std::max(nz, 1)) ||
       hipSuccess != pool().alloc((void**)&CN, sizeof(float) * (size_t)std::max(nz, 1)))
-    return cleanup(fail(SPGEMM_ERR_HIP, "device allocation failed"));
+    return hipfail("device allocation failed");
   if (m > 0 && nz > 0) {
     if (wide) hipLaunchKernelGGL(k_rmcl_compact<64>, dim3(grid), dim3(256), 0, s, m, dIC, dJC, dC, newPtr, th, ks, JN, CN);
     else hipLaunchKernelGGL(k_rmcl_compact<16>, dim3(grid), dim3(256), 0, s, m, dIC, dJC, dC, newPtr, th, ks, JN, CN);
-    HIPCHK(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) return hipfail("compaction launch");
   }
-  HIPCHK(hipStreamSynchronize(s));
+  if (hipStreamSynchronize(s) != hipSuccess) return hipfail("compaction");
   pool().release(th); pool().release(ks);
   *dIN = newPtr; *dJN = JN; *dCN = CN; *nnzN = nz;
   return SPGEMM_OK;
+}
+
+extern "C" int hip_rmcl_prune(spgemm_handle* h, int m, const int* dIC, const int* dJC, float* dC, int** dIN, int** dJN,
+                              float** dCN, int* nnzN) {
+  return rmcl_prune_impl(h, m, -1, dIC, dJC, dC, dIN, dJN, dCN, nnzN);
+}
+
+extern "C" int hip_rmcl_prune_n(spgemm_handle* h, int m, int nnz, const int* dIC, const int* dJC, const float* dC,
+                                int** dIN, int** dJN, float** dCN, int* nnzN) {
+  if (nnz < 0) return fail(SPGEMM_ERR_ARG, "negative nnz");
+  return rmcl_prune_impl(h, m, nnz, dIC, dJC, dC, dIN, dJN, dCN, nnzN);
 }
 
 extern "C" int hip_gpuRmclIter(int maxIter, int rows, int cols, const int* gIA, const int* gJA, const float* gA, int gnnz,
@@ -1034,7 +1085,7 @@ extern "C" int hip_gpuRmclIter(int maxIter, int rows, int cols, const int* gIA, 
     if ((rc = hip_gpuSpMM(h, dgI, dgJ, dgA, gnnz, dtI, dtJ, dtA, curnnz, rows, cols, cols, &cI, &cJ, &cA, &cn))) return cleanup(rc);
     int *nI = nullptr, *nJ = nullptr, nn = 0;
     float* nA = nullptr;
-    rc = hip_rmcl_prune(h, rows, cI, cJ, cA, &nI, &nJ, &nA, &nn);
+    rc = hip_rmcl_prune_n(h, rows, cn, cI, cJ, cA, &nI, &nJ, &nA, &nn);
     pool().release(cI); pool().release(cJ); pool().release(cA);
     if (rc) return cleanup(rc);
     pool().release(dtI); pool().release(dtJ); pool().release(dtA);
@@ -1058,12 +1109,32 @@ extern "C" int hip_csr_sort_rows(spgemm_handle* h, int m, const int* dIC, int* d
   if (m < 0 || !dIC) return fail(SPGEMM_ERR_ARG, "bad argument");
   if (!h) CHK(default_handle(&h));
   HIPCHK(hipSetDevice(h->device));
-  if (m > 0) {
-    hipLaunchKernelGGL(k_sort_rows, dim3(clampi(m, 1, h->numCU * 8)), dim3(256), 0, h->stream, m, dIC, dJC, dC);
-    HIPCHK(hipGetLastError());
+  if (m == 0) return SPGEMM_OK;
+  hipStream_t s = h->stream;
+  int* dcnt = nullptr;
+  int* JS = nullptr;
+  float* CS = nullptr;
+  auto cleanup = [&](int rc) { pool().release(dcnt); pool().release(JS); pool().release(CS); return rc; };
+  auto hipfail = [&](const char* what) { return cleanup(fail(SPGEMM_ERR_HIP, "sort rows: %s: %s", what, hipGetErrorString(hipGetLastError()))); };
+  if (pool().alloc((void**)&dcnt, sizeof(int)) != hipSuccess) return hipfail("allocation");
+  if (hipMemsetAsync(dcnt, 0, sizeof(int), s) != hipSuccess) return hipfail("memset");
+  hipLaunchKernelGGL(k_sort_rows, dim3(clampi(m, 1, h->numCU * 8)), dim3(256), 0, s, m, dIC, dJC, dC, dcnt);
+  int info[2] = {0, 0};                                // unsorted rows longer than SORT_MAX, nnz
+  if (hipMemcpyAsync(&info[0], dcnt, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipMemcpyAsync(&info[1], dIC + m, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return hipfail("short rows");
+  if (info[0] > 0 && info[1] > 0) {
+    // the long rows sort between their segment of (JC, C) and the same segment of a scratch copy
+    if (pool().alloc((void**)&JS, sizeof(int) * (size_t)info[1]) != hipSuccess ||
+        pool().alloc((void**)&CS, sizeof(float) * (size_t)info[1]) != hipSuccess)
+      return hipfail("scratch allocation");
+    // column bits: the columns of a valid CSR are < 2^31; take the width from the largest possible key
+    const int keyBits = 31;
+    hipLaunchKernelGGL(k_sort_long_rows, dim3(clampi(info[0], 1, h->numCU * 4)), dim3(256), 0, s, m, dIC, dJC, dC, JS, CS, keyBits);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return hipfail("long rows");
   }
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return SPGEMM_OK;
+  return cleanup(SPGEMM_OK);
 }
 
 extern "C" int spgemm_hip_selftest(spgemm_handle* h) {

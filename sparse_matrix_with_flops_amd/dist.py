@@ -102,11 +102,11 @@ class HipEngine:
         """One R-MCL step on this rank's rows: C = A*B (hip_gpuSpMM), then inflate/prune/normalise + compaction
         (hip_rmcl_prune), all on the device.  Returns torch tensors (rowPtr[rows+1], colInd, values)."""
         self.sync()
-        ic, jc, cv, _ = hs.gpu_spmm_raw(self.handle, _ptr(A["rowPtr"]), _ptr(A["colInd"]), _ptr(A["values"]), A["nnz"],
+        ic, jc, cv, nnzc = hs.gpu_spmm_raw(self.handle, _ptr(A["rowPtr"]), _ptr(A["colInd"]), _ptr(A["values"]), A["nnz"],
                                         _ptr(B["rowPtr"]), _ptr(B["colInd"]), _ptr(B["values"]), B["nnz"],
                                         A["rows"], A["cols"], B["cols"])
         try:
-            pi, pj, pv, nn = hs.rmcl_prune_raw(self.handle, A["rows"], ic, jc, cv)
+            pi, pj, pv, nn = hs.rmcl_prune_raw(self.handle, A["rows"], ic, jc, cv, nnz=nnzc)
         finally:
             for p in (ic, jc, cv):
                 hs.dev_free(p)

@@ -35,6 +35,7 @@ EXPORTS = [
     "hip_gpuFlopsClassify", "hip_sgpuSpMM", "hip_csr_sort_rows", "spgemm_hip_selftest",
     "hip_spgemm_symbolic", "hip_spgemm_numeric", "hip_csr_row_flops", "spgemm_hip_kernel_name",
     "hip_rmcl_prune", "hip_gpuRmclIter", "hip_coo_to_csr", "hip_flopsStats", "spgemm_hip_set_kernel_timing",
+    "hip_rmcl_prune_n", "spgemm_hip_pool_cached_bytes",
 ]
 
 
@@ -101,6 +102,9 @@ def lib():
         L.spgemm_hip_memcpy_d2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.hip_rmcl_prune.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + \
             [C.POINTER(C.c_void_p)] * 3 + [_I]
+        L.hip_rmcl_prune_n.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + \
+            [C.POINTER(C.c_void_p)] * 3 + [_I]
+        L.spgemm_hip_pool_cached_bytes.argtypes = [C.c_int, C.POINTER(C.c_size_t)]
         L.hip_gpuRmclIter.argtypes = [C.c_int, C.c_int, C.c_int, _I, _I, _F, C.c_int, _I, _I, _F, C.c_int,
                                       C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I]
         L.hip_csr_sort_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -303,13 +307,25 @@ def d2d(dst, src, nbytes):
     _check(lib().spgemm_hip_memcpy_d2d(C.c_void_p(dst), C.c_void_p(src), int(nbytes)), "spgemm_hip_memcpy_d2d")
 
 
-def rmcl_prune_raw(handle, m, IC, JC, CV):
+def rmcl_prune_raw(handle, m, IC, JC, CV, nnz=None):
     """hip_rmcl_prune on raw device pointers: inflate/prune/normalise the rows of C, compacted into new pool arrays.
+    nnz (optional): nnz(C) when the caller knows it (hip_rmcl_prune_n: no device read for it).
     Returns (IN, JN, CN, nnzN); release the three with dev_free."""
     i_, j_, c_, n_ = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
-    _check(lib().hip_rmcl_prune(handle.ptr if handle else None, int(m), C.c_void_p(IC), C.c_void_p(JC), C.c_void_p(CV),
-                                C.byref(i_), C.byref(j_), C.byref(c_), C.byref(n_)), "hip_rmcl_prune")
+    hp = handle.ptr if handle else None
+    if nnz is None:
+        _check(lib().hip_rmcl_prune(hp, int(m), C.c_void_p(IC), C.c_void_p(JC), C.c_void_p(CV),
+                                    C.byref(i_), C.byref(j_), C.byref(c_), C.byref(n_)), "hip_rmcl_prune")
+    else:
+        _check(lib().hip_rmcl_prune_n(hp, int(m), int(nnz), C.c_void_p(IC), C.c_void_p(JC), C.c_void_p(CV),
+                                      C.byref(i_), C.byref(j_), C.byref(c_), C.byref(n_)), "hip_rmcl_prune_n")
     return i_.value, j_.value, c_.value, n_.value
+
+
+def pool_cached_bytes(device=0):
+    n = C.c_size_t(0)
+    _check(lib().spgemm_hip_pool_cached_bytes(int(device), C.byref(n)), "spgemm_hip_pool_cached_bytes")
+    return int(n.value)
 
 
 COO_DEDUPE, COO_SELF_LOOPS, COO_ROW_NORMALISE, COO_ABS = 1, 2, 4, 8

@@ -112,3 +112,79 @@ def random_csr(rows, cols, density, seed, sorted_rows=True, signed=True):
             ci[s:e] = ci[s:e][p]
             v[s:e] = v[s:e][p]
     return po.CSRHost(rp, ci, v, rows, cols)
+
+
+# ---------------------------------------------------------------------------------------------
+# R-MCL: one step  Mt' = prune(Mgt * Mt)  of a device implementation against the oracle, with the threshold ties
+# accounted for explicitly ("recompute the threshold, assert that every entry kept on one side only lies
+# within a few float32 ulps of it, and that all other entries match at 1e-6; report the number of differing rows").
+# ---------------------------------------------------------------------------------------------
+def rmcl_thresholds(Cm):
+    """Per row of the raw product Cm: the reference's prune threshold (nlibs/tools/util.cc:4-9 computeThreshold on the
+    float32 max and average of the inflated (squared) values), plus the squared values."""
+    rp = np.asarray(Cm.rowPtr, dtype=np.int64)
+    v2 = (np.asarray(Cm.values, dtype=np.float32) ** 2).astype(np.float32)
+    n = np.diff(rp)
+    th = np.zeros(len(n), dtype=np.float32)
+    live = n > 0
+    if live.any():
+        mx = np.maximum.reduceat(v2, rp[:-1][live])
+        avg = (np.add.reduceat(v2.astype(np.float64), rp[:-1][live]) / n[live]).astype(np.float32)
+        t = (0.90 * avg.astype(np.float64) * (1 - 2 * (mx.astype(np.float64) - avg.astype(np.float64)))).astype(np.float32)
+        t = np.where(t > 1.0e-7, t, np.float32(1.0e-7)).astype(np.float32)
+        th[live] = np.minimum(t, mx)
+    return th, v2
+
+
+def rmcl_tie_rows(Cm, ulps=4):
+    """Rows with at least one entry whose squared value is within `ulps` float32 ulps of the row's threshold."""
+    th, v2 = rmcl_thresholds(Cm)
+    rp = np.asarray(Cm.rowPtr, dtype=np.int64)
+    thr = np.repeat(th, np.diff(rp))
+    near = np.abs(v2.astype(np.float64) - thr.astype(np.float64)) <= ulps * np.spacing(np.maximum(thr, np.float32(1e-30))).astype(np.float64)
+    return np.unique(np.repeat(np.arange(len(th)), np.diff(rp))[near])
+
+
+def assert_rmcl_step(got, Mgt, Mt, rel=1e-6, ulps=4, what=""):
+    """got = device result of one R-MCL step from (Mgt, Mt).  Every row either equals the oracle's row (same kept
+    columns, values within `rel`) or differs ONLY in entries that sit within `ulps` float32 ulps of the prune threshold
+    (the device sums a row in another order than the sequential CPU loop).  Returns the number of differing rows."""
+    import ctypes as C
+    Cm = po.omp_spmm(Mgt, Mt)
+    rp, ci, v = Cm.rowPtr.copy(), Cm.colInd.copy(), Cm.values.copy()
+    n = po.lib().oracle_rmcl_prune_compact(C.c_int(Cm.rows), po._ip(rp), po._ip(ci), po._fp(v))
+    want = po.CSRHost(rp, ci[:n], v[:n], Cm.rows, Cm.cols)
+    assert got.rows == want.rows
+    gc, gv = _canon(got)
+    wc, wv = _canon(want)
+    grp, wrp = np.asarray(got.rowPtr, dtype=np.int64), np.asarray(want.rowPtr, dtype=np.int64)
+    gl, wl = np.diff(grp), np.diff(wrp)
+
+    def row_sig(rp_, c_):
+        h = np.zeros(len(rp_) - 1, dtype=np.uint64)
+        live = np.diff(rp_) > 0
+        mixed = (c_.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ (c_.astype(np.uint64) << np.uint64(17))
+        if live.any():
+            with np.errstate(over="ignore"):
+                h[live] = np.add.reduceat(mixed, rp_[:-1][live])
+        return h
+    diff = np.nonzero((gl != wl) | (row_sig(grp, gc) != row_sig(wrp, wc)))[0]
+    th, v2 = rmcl_thresholds(Cm)
+    crp = np.asarray(Cm.rowPtr, dtype=np.int64)
+    for r in diff:                                                # few rows: each must be a threshold tie
+        cols_raw = np.asarray(Cm.colInd[crp[r]:crp[r + 1]])
+        sq = v2[crp[r]:crp[r + 1]]
+        gset, wset = set(gc[grp[r]:grp[r + 1]].tolist()), set(wc[wrp[r]:wrp[r + 1]].tolist())
+        assert gset <= set(cols_raw.tolist()), f"{what}: row {r} holds a column that is not in the product"
+        for c in gset ^ wset:
+            x = float(sq[cols_raw == c][0])
+            lim = ulps * float(np.spacing(np.float32(max(th[r], 1e-30))))
+            assert abs(x - float(th[r])) <= lim, f"{what}: row {r} col {c}: v^2={x!r} vs threshold {float(th[r])!r} is not a tie"
+    same_row = np.ones(len(gl), dtype=bool)
+    same_row[diff] = False
+    gm, wm = np.repeat(same_row, gl), np.repeat(same_row, wl)
+    assert np.array_equal(gc[gm], wc[wm]), f"{what}: kept columns differ outside the tie rows"
+    a, b = gv[gm].astype(np.float64), wv[wm].astype(np.float64)
+    bad = np.abs(a - b) > rel * np.maximum(np.abs(a), np.abs(b))
+    assert not bad.any(), f"{what}: {int(bad.sum())} values beyond {rel} relative (worst {np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)):.2e})"
+    return len(diff), want

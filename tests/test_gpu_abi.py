@@ -1,0 +1,122 @@
+"""GPU (-m gpu): behaviour of the C ABI around the kernels -- the caching allocator (per device, idle blocks only),
+the two-phase protocol (a pending symbolic phase dies with any other use of the handle's workspace) and the
+classification scan beyond 2^31 products."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import po, synth_csr
+from sparse_matrix_with_flops_amd import hipspgemm as hs
+from test_gpu_parity import to_hs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import __graft_entry__ as ge
+    ge.build()
+    assert hs.device_count() >= 1
+
+
+def test_pool_is_per_device_and_trimmed_with_the_last_handle():
+    """Blocks freed on a device are cached for THAT device and reused there; destroying the last handle of the device
+    gives them back to the driver.  (With one GPU visible the cross-device case cannot run; the keying is by
+    hipGetDevice() at allocation and the stored device at release.)"""
+    h = hs.Handle(0)
+    a = hs.dev_alloc(8 << 20)
+    hs.dev_free(a)
+    cached = hs.pool_cached_bytes(0)
+    assert cached >= (8 << 20)
+    b = hs.dev_alloc(8 << 20)                       # comes out of the cache (best fit: this block or an older one)
+    assert hs.pool_cached_bytes(0) <= cached - (8 << 20)
+    hs.dev_free(b)
+    if hs.device_count() > 1:
+        assert hs.pool_cached_bytes(1) == 0        # nothing was ever freed on device 1
+        h1 = hs.Handle(1)                           # hipSetDevice(1): an allocation now must not get device 0's block
+        c = hs.dev_alloc(8 << 20)
+        assert c not in (a, b) and hs.pool_cached_bytes(0) >= (8 << 20)
+        hs.dev_free(c)
+        h1.close()
+        hs.lib().spgemm_hip_create(C.byref(C.c_void_p()), 0)   # back to device 0 for the rest of the session
+    import gc
+    gc.collect()
+    others = hs.pool_cached_bytes(0)
+    h.close()
+    # default handles of other tests may still be alive on device 0; if this was the last one the cache is empty
+    assert hs.pool_cached_bytes(0) in (0, others)
+
+
+def test_entry_points_complete_their_work_before_returning():
+    """The pool's invariant: an entry point returns only after its stream work is done, so freeing C right after the
+    call and reusing the block cannot race with the kernels that wrote it.  Run SpGEMM, copy C out, free it, let another
+    SpGEMM reuse the same blocks, and check the first copy is still the right answer."""
+    h = hs.Handle(0)
+    A, B = synth_csr(30000, 5, 2), synth_csr(30000, 6, 2)
+    dA, dB = to_hs(A).toGpuCSR(), to_hs(B).toGpuCSR()
+    c1 = hs.gpuSpMMWrapper(dA, dA, h)
+    first = c1.toCpuCSR()
+    ptrs = (c1.rowPtr, c1.colInd, c1.values)
+    c1.deviceDispose()
+    c2 = hs.gpuSpMMWrapper(dB, dB, h)               # same sizes class: the pool hands the freed blocks out again
+    assert {c2.rowPtr, c2.colInd, c2.values} & set(ptrs), "expected the cached blocks to be reused"
+    second = c2.toCpuCSR()
+    c2.deviceDispose()
+    from helpers import assert_parity
+    assert_parity(first, po.omp_spmm(A, A), what="first product")
+    assert_parity(second, po.omp_spmm(B, B), what="second product")
+    dA.deviceDispose(); dB.deviceDispose()
+
+
+def test_pending_symbolic_phase_is_invalidated_by_other_calls():
+    """symbolic -> row_flops on a DIFFERENT matrix -> numeric must fail with SPGEMM_ERR_ARG instead of running the
+    numeric kernels on the other matrix's bins."""
+    h = hs.Handle(0)
+    A, B = synth_csr(20000, 7, 2), synth_csr(20000, 8, 2)
+    dA, dB = to_hs(A).toGpuCSR(), to_hs(B).toGpuCSR()
+    dIC = hs.dev_alloc(4 * (A.rows + 1))
+    nnz = hs.spgemm_symbolic_raw(h, dA.rowPtr, dA.colInd, A.nnz, dA.rowPtr, dA.colInd, A.nnz, A.rows, A.cols, A.cols, dIC)
+    tmp = hs.dev_alloc(4 * B.rows)
+    hs.row_flops_raw(h, dB.rowPtr, dB.colInd, dB.rowPtr, B.rows, tmp)
+    dJC, dC = hs.dev_alloc(4 * max(nnz, 1)), hs.dev_alloc(4 * max(nnz, 1))
+    with pytest.raises(hs.SpgemmError, match="status 2"):
+        hs.spgemm_numeric_raw(h, dA.rowPtr, dA.colInd, dA.values, A.nnz, dA.rowPtr, dA.colInd, dA.values, A.nnz,
+                              A.rows, A.cols, A.cols, dIC, dJC, dC)
+    # and the protocol still works afterwards
+    nnz = hs.spgemm_symbolic_raw(h, dA.rowPtr, dA.colInd, A.nnz, dA.rowPtr, dA.colInd, A.nnz, A.rows, A.cols, A.cols, dIC)
+    hs.spgemm_numeric_raw(h, dA.rowPtr, dA.colInd, dA.values, A.nnz, dA.rowPtr, dA.colInd, dA.values, A.nnz,
+                          A.rows, A.cols, A.cols, dIC, dJC, dC)
+    for p in (dIC, tmp, dJC, dC):
+        hs.dev_free(p)
+    dA.deviceDispose(); dB.deviceDispose()
+
+
+def test_classification_scan_is_consistent_beyond_2_pow_31_products():
+    """dflops is an int32 scan like the reference's (flops.cu:119,133) whose consumers take DIFFERENCES: with
+    P > 2^31 the prefixes wrap modulo 2^32 -- including the last one, which used to be clamped to INT_MAX and made the
+    last row's count wrong.  A fabricated B.rowPtr (row lengths of 5e8..7e8) makes this cheap: the classification never
+    touches B's columns."""
+    m = 8
+    IA = np.arange(m + 1, dtype=np.int32)                     # one entry per row, column = row
+    JA = np.arange(m, dtype=np.int32)
+    lens = np.array([700_000_000, 3, 600_000_000, 0, 7, 650_000_000, 1, 500_000_001], dtype=np.int64)
+    IBfake = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(lens, out=IBfake[1:])
+    assert IBfake[-1] > 2**31 and IBfake[-1] < 2**32
+    IB32 = IBfake.astype(np.uint32).view(np.int32)            # B.rowPtr as the int32 bit patterns (differences are exact mod 2^32)
+    # row lengths must be < 2^31 individually for the flops kernel: they are
+    h = hs.Handle(0)
+    dIA, dJA, dIB = hs.h2d(IA), hs.h2d(JA), hs.h2d(IB32)
+    ids, fl, hv = C.c_void_p(), C.c_void_p(), (C.c_int * hs.HV_LEN)()
+    hvl, tot = C.c_int(0), C.c_longlong(0)
+    rc = hs.lib().hip_gpuFlopsClassify(h.ptr, C.c_void_p(dIA), C.c_void_p(dJA), C.c_void_p(dIB), m, m, C.byref(ids),
+                                       C.byref(fl), hv, C.byref(hvl), C.byref(tot))
+    assert rc == 0, hs.lib().spgemm_hip_last_error()
+    rowIds = hs.d2h(ids.value, m, np.int32)
+    dfl = hs.d2h(fl.value, m + 1, np.int32).view(np.uint32).astype(np.int64)
+    per = (dfl[1:] - dfl[:-1]) % (1 << 32)
+    assert tot.value == int(lens.sum())
+    assert np.array_equal(per, lens[rowIds]), (per, lens[rowIds])     # every row, the last one included
+    for p in (dIA, dJA, dIB, ids.value, fl.value):
+        hs.dev_free(p)

@@ -112,6 +112,28 @@ def test_headline_config_device_resident(handle):
     assert s["hash"] == g["hash"] and abs(s["sum"] - g["sum"]) <= 1e-6 * abs(g["sum"])
 
 
+def test_device_makeOrdered_long_unsorted_rows(handle):
+    """hip_csr_sort_rows on an output whose big rows come out of the LDS hash kernel UNSORTED and are longer than the
+    4096-entry bitonic tile (n > 262 144 columns: no rank kernel): the per-row radix sort must give exactly
+    CSR::makeOrdered's result (columns ascending, values carried along)."""
+    A = synth_csr(300000, 5, 2)
+    dA = to_hs(A).toGpuCSR()
+    dC = hs.gpuSpMMWrapper(dA, dA, handle)
+    raw = dC.toCpuCSR()
+    lens = np.diff(raw.rowPtr)
+    long_rows = np.nonzero(lens > 4096)[0]
+    assert len(long_rows) > 100
+    unsorted_long = sum(bool(np.any(np.diff(raw.colInd[raw.rowPtr[r]:raw.rowPtr[r + 1]]) < 0)) for r in long_rows[:200])
+    assert unsorted_long > 0, "expected unsorted long rows from the hash kernel"
+    hs.sort_rows_device(dC, handle)
+    srt = dC.toCpuCSR()
+    dC.deviceDispose()
+    dA.deviceDispose()
+    cs, vs = canonical_arrays(raw.rowPtr, raw.colInd, raw.values)
+    assert np.array_equal(srt.rowPtr, raw.rowPtr)
+    assert np.array_equal(srt.colInd, cs) and np.array_equal(srt.values.view(np.uint32), vs.view(np.uint32))
+
+
 def test_bench_workload_1m_rows_vs_reference_summary(handle):
     """bench.py's default workload (1 048 576 rows, seed 43; columns exceed the 262 144-column rank kernel, so rows
     above 4096 products take the LDS hash kernel incl. multi-pass rows that park products in HBM) against the summary
@@ -128,6 +150,46 @@ def test_bench_workload_1m_rows_vs_reference_summary(handle):
     s = summarize(got)
     assert s["nnz"] == g["nnz"] and s["hash"] == g["hash"]
     assert abs(s["sum"] - g["sum"]) <= 1e-6 * abs(g["sum"]) and abs(s["wsum"] - g["wsum"]) <= 1e-6 * abs(g["wsum"])
+
+
+def test_config3_1m_rows_32_per_row_vs_reference_summary(handle):
+    """BASELINE configs[3] on ONE GPU (the row-sharded form is tests/test_gpu_dist.py + bench.py --gpus N): synthetic
+    1 048 576^2, ~32 nnz/row (seed 44, base 4), P = 0.89 G products, against the summary the real reference's
+    omp_CSR_SpMM produced (tests/golden/golden_large.json, tests/golden/make_golden_large.py)."""
+    import json
+    g = json.load(open(os.path.join(GOLDEN, "golden_large.json")))["synth_1048576_44_4"]
+    A = synth_csr(g["m"], g["seed"], g["base"])
+    assert A.nnz == g["nnzA"]
+    dA = to_hs(A).toGpuCSR()
+    dC = hs.gpuSpMMWrapper(dA, dA, handle)
+    st = handle.stats()
+    assert st["total_flops"] == g["P"] and st["nnzC"] == g["nnz"]
+    got = dC.toCpuCSR()
+    dC.deviceDispose()
+    dA.deviceDispose()
+    s = summarize(got)
+    assert s["nnz"] == g["nnz"] and s["hash"] == g["hash"]
+    assert abs(s["sum"] - g["sum"]) <= 1e-6 * abs(g["sum"]) and abs(s["wsum"] - g["wsum"]) <= 1e-6 * abs(g["wsum"])
+    # the 8-way flops partition the sharded run would use (arrayEqualPartition64 of the reference)
+    flops = po.row_flops(A, A)
+    prefix = np.concatenate([[0], np.cumsum(flops)]).astype(np.int64)
+    from sparse_matrix_with_flops_amd.dist import equal_partition64
+    assert [int(x) for x in equal_partition64(prefix, 8)] == g["partition8"]
+
+
+@pytest.mark.skipif(not os.environ.get("SPGEMM_WEB_GOOGLE_MTX"), reason="set SPGEMM_WEB_GOOGLE_MTX=/path/to/web-Google.mtx")
+def test_config2_web_google_known_totals(handle):
+    """BASELINE configs[2]: SuiteSparse web-Google is on neither box; when a copy is supplied by environment variable,
+    A*A must reproduce the totals the reference tree records for it (tools/res.txt:1910)."""
+    k = META["survey_known_answers"]["res_txt_web_google"]
+    A = po.load(os.environ["SPGEMM_WEB_GOOGLE_MTX"], isTrans=False, mode=0)
+    assert A.rows == k["N"] and A.nnz == k["nnzA"]
+    dA = to_hs(A).toGpuCSR()
+    dC = hs.gpuSpMMWrapper(dA, dA, handle)
+    st = handle.stats()
+    dC.deviceDispose()
+    dA.deviceDispose()
+    assert st["nnzC"] == k["nnzC"] and 2 * st["total_flops"] == k["flops"]
 
 
 def test_classify_matches_oracle(handle):

@@ -1,13 +1,14 @@
 """GPU (-m gpu): the R-MCL caller of the hot path — device prune step + gpuRmclIter — against the
 oracle's seqRmclIter restatement and the golden R-MCL results made from the real reference; plus the C++ mirror
 driven by the reference-style test program tests/cpp/testGpuSpMM.cc."""
+import json
 import os
 import subprocess
 
 import numpy as np
 import pytest
 
-from helpers import DATA, GOLDEN, ROOT, canonical_arrays, po, synth_csr
+from helpers import DATA, GOLDEN, ROOT, assert_rmcl_step, canonical_arrays, po, rmcl_tie_rows, synth_csr
 from sparse_matrix_with_flops_amd import hipspgemm as hs
 from test_gpu_parity import FX, SQUARE, to_hs, unpack
 
@@ -35,33 +36,68 @@ def test_rmcl_fixtures_match_reference_goldens(name, iters):
     gr, gc, gv = ordered(got)
     wr, wc, wv = ordered(want)
     assert np.array_equal(gr, wr) and np.array_equal(gc, wc)
-    assert np.allclose(gv, wv, rtol=1e-5, atol=1e-7)
+    assert np.allclose(gv, wv, rtol=1e-6, atol=0.0)                       # north_star: values within 1e-6 relative
+
+
+def _graph(m, seed):
+    A = synth_csr(m, seed, 2)
+    ri = np.repeat(np.arange(A.rows, dtype=np.int32), np.diff(A.rowPtr))
+    return po.rmcl_init(A.rows, A.cols, A.colInd, ri, np.ones_like(A.values))     # transpose + self loops + row-normalise
+
+
+def _device_steps(Mt, iters):
+    """The device-resident loop one step at a time (hip_gpuSpMM + hip_rmcl_prune per step): yields (k, Mt_k, Mt_k+1)."""
+    import torch
+    from sparse_matrix_with_flops_amd.dist import HipEngine, make_matrix
+    eng = HipEngine(0)
+    Mg = make_matrix(eng, Mt.rowPtr, Mt.colInd, Mt.values, Mt.rows, Mt.cols)
+    cur_dev, cur_host = Mg, Mt
+    for k in range(iters):
+        rp, ci, v = eng.expand_prune(Mg, cur_dev)
+        torch.cuda.synchronize()
+        nxt_host = po.CSRHost(rp.cpu().numpy(), ci.cpu().numpy(), v.cpu().numpy(), Mt.rows, Mt.cols)
+        yield k, cur_host, nxt_host
+        cur_dev = {"rowPtr": rp, "colInd": ci, "values": v, "rows": Mt.rows, "cols": Mt.cols, "nnz": int(ci.numel())}
+        cur_host = nxt_host
 
 
 def test_rmcl_synthetic_graph_three_iterations():
-    """Power-law graph, 3 iterations.  The prune threshold comes from float sums whose order differs between the
-    CPU loop and the device reduction, so an entry within an ulp of the threshold may be kept on one side only:
-    rows may differ in a vanishing fraction, everything else must agree."""
-    A = synth_csr(20000, 91, 2)
-    ones = po.CSRHost(A.rowPtr, A.colInd, np.ones_like(A.values), A.rows, A.cols)
-    rows, cols, ri = A.rows, A.cols, np.repeat(np.arange(A.rows, dtype=np.int32), np.diff(A.rowPtr))
-    Mt = po.rmcl_init(rows, cols, A.colInd, ri, ones.values)              # transpose + self loops + row-normalise
-    got = hs.gpuRmclIter(3, to_hs(Mt), to_hs(Mt))
-    want = po.rmcl_iters(Mt, Mt, 3)
-    gl, wl = np.diff(got.rowPtr), np.diff(want.rowPtr)
-    assert np.mean(gl != wl) < 1e-3
-    assert abs(int(got.nnz) - int(want.nnz)) <= max(20, want.nnz // 2000)
-    same = np.nonzero(gl == wl)[0][:2000]
-    for r in same:
-        g0, w0 = got.rowPtr[r], want.rowPtr[r]
-        gc = np.sort(got.colInd[g0:g0 + gl[r]])
-        wc = np.sort(want.colInd[w0:w0 + wl[r]])
-        if np.array_equal(gc, wc):
-            gv = got.values[g0:g0 + gl[r]][np.argsort(got.colInd[g0:g0 + gl[r]])]
-            wv = want.values[w0:w0 + wl[r]][np.argsort(want.colInd[w0:w0 + wl[r]])]
-            assert np.allclose(gv, wv, rtol=1e-4, atol=1e-7)
-    rs = np.add.reduceat(got.values, got.rowPtr[:-1][gl > 0])
-    assert np.allclose(rs, 1.0, atol=1e-4)                                # every row is a distribution again
+    """Power-law graph, 3 iterations, every step checked against the oracle from the device's own previous state: rows
+    are identical (kept columns bit-exact, values 1e-6) except where an entry sits within 4 float32 ulps of the prune
+    threshold -- the device sums a row in another order than the sequential CPU loop.  The number of such rows is
+    counted and bounded by the number of rows that HAVE such an entry."""
+    Mt = _graph(20000, 91)
+    for k, cur, nxt in _device_steps(Mt, 3):
+        ndiff, want = assert_rmcl_step(nxt, Mt, cur, what=f"iteration {k + 1}")
+        ties = len(rmcl_tie_rows(po.omp_spmm(Mt, cur)))
+        print(f"iteration {k + 1}: {ndiff} rows differ from the oracle, {ties} rows hold a threshold tie, nnz {nxt.nnz} vs {want.nnz}")
+        assert ndiff <= ties
+        gl = np.diff(nxt.rowPtr)
+        rs = np.add.reduceat(nxt.values.astype(np.float64), nxt.rowPtr[:-1][gl > 0])
+        assert np.allclose(rs, 1.0, atol=1e-5)                            # every row is a distribution again
+
+
+def test_config4_rmcl_500k_nodes_ten_iterations():
+    """BASELINE configs[4] on one GPU: 500 000-node power-law graph (seed 45), 10 iterations of the device-resident
+    loop.  Per iteration: (1) the step from the device's own state equals the oracle's step up to counted threshold
+    ties (assert_rmcl_step), (2) rows sum to 1, (3) nnz follows the per-iteration summary in golden_large.json (made
+    with the reference-pinned kernels and cross-checked against RMCL(file, 10, OMP) of the real reference) within the
+    drift the ties allow."""
+    G = json.load(open(os.path.join(GOLDEN, "golden_large.json")))["rmcl_500000_45"]
+    Mt = _graph(G["m"], G["seed"])
+    assert Mt.nnz == G["nnz0"]
+    total_ties = 0
+    for k, cur, nxt in _device_steps(Mt, G["iters"]):
+        ndiff, want = assert_rmcl_step(nxt, Mt, cur, what=f"iteration {k + 1}")
+        g = G["per_iter"][k]
+        total_ties += g["tie_rows"] + ndiff
+        gl = np.diff(nxt.rowPtr)
+        rs = np.add.reduceat(nxt.values.astype(np.float64), nxt.rowPtr[:-1][gl > 0])
+        print(f"iteration {k + 1}: nnz {nxt.nnz} (golden {g['nnz']}), {ndiff} tie rows differ from the oracle step")
+        assert np.allclose(rs, 1.0, atol=1e-5)
+        assert ndiff <= max(8, 4 * g["tie_rows"] + 8)
+        # a flipped tie changes later iterations a little: nnz stays within 0.05 % + the ties seen so far
+        assert abs(int(nxt.nnz) - g["nnz"]) <= 5e-4 * g["nnz"] + 64 * (total_ties + 1)
 
 
 def test_sharded_rmcl_single_rank_matches_gpuRmclIter():
