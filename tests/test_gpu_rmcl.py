@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import DATA, GOLDEN, ROOT, assert_rmcl_step, canonical_arrays, po, rmcl_tie_rows, synth_csr
+from helpers import DATA, GOLDEN, ROOT, assert_rmcl_step, canonical_arrays, po, synth_csr
 from sparse_matrix_with_flops_amd import hipspgemm as hs
 from test_gpu_parity import FX, SQUARE, to_hs, unpack
 
@@ -68,10 +68,8 @@ def test_rmcl_synthetic_graph_three_iterations():
     counted and bounded by the number of rows that HAVE such an entry."""
     Mt = _graph(20000, 91)
     for k, cur, nxt in _device_steps(Mt, 3):
-        ndiff, want = assert_rmcl_step(nxt, Mt, cur, what=f"iteration {k + 1}")
-        ties = len(rmcl_tie_rows(po.omp_spmm(Mt, cur)))
+        ndiff, ties, want = assert_rmcl_step(nxt, Mt, cur, what=f"iteration {k + 1}")
         print(f"iteration {k + 1}: {ndiff} rows differ from the oracle, {ties} rows hold a threshold tie, nnz {nxt.nnz} vs {want.nnz}")
-        assert ndiff <= ties
         gl = np.diff(nxt.rowPtr)
         rs = np.add.reduceat(nxt.values.astype(np.float64), nxt.rowPtr[:-1][gl > 0])
         assert np.allclose(rs, 1.0, atol=1e-5)                            # every row is a distribution again
@@ -88,14 +86,13 @@ def test_config4_rmcl_500k_nodes_ten_iterations():
     assert Mt.nnz == G["nnz0"]
     total_ties = 0
     for k, cur, nxt in _device_steps(Mt, G["iters"]):
-        ndiff, want = assert_rmcl_step(nxt, Mt, cur, what=f"iteration {k + 1}")
+        ndiff, ties, want = assert_rmcl_step(nxt, Mt, cur, what=f"iteration {k + 1}")
         g = G["per_iter"][k]
-        total_ties += g["tie_rows"] + ndiff
+        total_ties += ndiff
         gl = np.diff(nxt.rowPtr)
         rs = np.add.reduceat(nxt.values.astype(np.float64), nxt.rowPtr[:-1][gl > 0])
-        print(f"iteration {k + 1}: nnz {nxt.nnz} (golden {g['nnz']}), {ndiff} tie rows differ from the oracle step")
+        print(f"iteration {k + 1}: nnz {nxt.nnz} (golden {g['nnz']}), {ndiff} of {ties} tie rows differ from the oracle step")
         assert np.allclose(rs, 1.0, atol=1e-5)
-        assert ndiff <= max(8, 4 * g["tie_rows"] + 8)
         # a flipped tie changes later iterations a little: nnz stays within 0.05 % + the ties seen so far
         assert abs(int(nxt.nnz) - g["nnz"]) <= 5e-4 * g["nnz"] + 64 * (total_ties + 1)
 
