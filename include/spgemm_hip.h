@@ -203,6 +203,28 @@ int hip_coo_to_csr(spgemm_handle* h, int rows, int cols, int nnz, const int* dRo
 #define SPGEMM_STATS_LEN 13
 int hip_flopsStats(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, int m, int stats[SPGEMM_STATS_LEN]);
 
+/* vector<int> CSR::nnzStats() (nlibs/CSR.cc:241-248, pushToStats nlibs/tools/stats.cc:3-12): 18 power-of-two buckets of
+ * the row lengths of a device CSR (dIA = rowPtr[m+1]). */
+#define SPGEMM_NNZ_STATS_LEN 18
+int hip_nnzStats(spgemm_handle* h, const int* dIA, int m, int stats[SPGEMM_NNZ_STATS_LEN]);
+
+/* Per-bin correctness report: bool resultsComparison(CSR& hC, CSR& rC, const vector<int>& hv, const int* hqueue) with
+ * isPartialRawEqual per bin (mindex2-cuda/nGpuSpMM.cc:85-240).  HOST arrays: hC = result under test, rC = reference
+ * result (same shape m x n), hv/hqueue = bin boundaries and row queue as returned by hip_gpuFlopsClassify (queue copied
+ * to the host).  report[b] describes reference bin b+1 (0 / 1 / 2-4 / 5-16 / 17-64 / 65-512 / >512 products):
+ * rows compared, rows that differ (length, a column, or a value beyond `rel` relative), the first such row, and the
+ * largest relative value error seen on common columns. */
+typedef struct spgemm_bin_report {
+  int rows;
+  int rows_differ;
+  int first_bad_row;        /* -1 if none */
+  double max_rel_err;
+} spgemm_bin_report;
+int hip_resultsComparison(int m, int n, const int* hIC, const int* hJC, const float* hC,
+                          const int* rIC, const int* rJC, const float* rC,
+                          const int hv[SPGEMM_HV_LEN], int hv_len, const int* hqueue, double rel,
+                          spgemm_bin_report report[SPGEMM_HV_LEN - 1]);
+
 /* ---- helpers the reference's drivers use around the path --------------------------------------- */
 /* CSR::makeOrdered on device arrays (nlibs/CSR.cc:73-86): sort every row by column, in place. */
 int hip_csr_sort_rows(spgemm_handle* h, int m, const int* dIC, int* dJC, float* dC);

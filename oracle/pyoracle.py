@@ -203,6 +203,35 @@ def ref_equal_partition64(prefix, parts):
     return ends
 
 
+def footprints(A, B, counts=None):
+    """Restatement of footPrintsCrowiCount (nlibs/static_omp_csr_kernel.cc:28-62): per row of C = A*B
+    (flops + nnzC_row + 32 + nnzA_row) >> 1, 0 for an empty A row; returns the exclusive prefix [m+1] (int64)."""
+    fl = row_flops(A, B).astype(np.int64)
+    if counts is None:
+        counts = np.diff(omp_spmm(A, B).rowPtr)
+    na = np.diff(A.rowPtr).astype(np.int64)
+    fp = np.where(na > 0, (fl + np.asarray(counts, dtype=np.int64) + 32 + na) >> 1, 0)
+    out = np.zeros(A.rows + 1, dtype=np.int64)
+    np.cumsum(fp, out=out[1:])
+    return out
+
+
+def ref_footprints(A, B, stride=512):
+    """-> (C.rowPtr, footprint prefix) from the real reference (dynamic_omp_CSR_IC_nnzC_footprints)."""
+    ic = np.zeros(A.rows + 1, dtype=np.int32)
+    fp = np.zeros(A.rows + 1, dtype=np.int32)
+    ref().ref_footprints(_ip(A.rowPtr), _ip(A.colInd), _ip(B.rowPtr), _ip(B.colInd), C.c_int(A.rows), C.c_int(B.cols),
+                         _ip(ic), _ip(fp), C.c_int(stride))
+    return ic, fp
+
+
+def ref_equal_partition(prefix, parts):
+    prefix = np.ascontiguousarray(prefix, dtype=np.int32).copy()
+    ends = np.zeros(parts + 1, dtype=np.int32)
+    ref().ref_equal_partition(_ip(prefix), C.c_int(len(prefix) - 1), C.c_int(parts), _ip(ends))
+    return ends
+
+
 def group_bins(A, B):
     rf = np.zeros(A.rows + 1, dtype=np.int32)
     groups = np.zeros(A.rows + 1, dtype=np.int32)

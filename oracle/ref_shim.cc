@@ -17,6 +17,7 @@
 //   dynamic_omp_CSR_flops      nlibs/flops_csr_kernel.cc:14-31
 //   group_CSR_flops            nlibs/group_csr_kernel.cc:10-52
 //   arrayEqualPartition64      nlibs/tools/util.cc:123-135
+//   dynamic_omp_CSR_IC_nnzC_footprints / arrayEqualPartition   nlibs/static_omp_csr_kernel.cc:28-95, tools/util.cc:109-121
 //   COO::readSNAPFile/orderedAndDuplicatesRemoving/toCSR  nlibs/COO.cc:48-291
 //   rmclInit / RMCL            nlibs/qrmcl.cc:126-164
 //   CSR::makeOrdered / isEqual nlibs/CSR.cc:73-86, nlibs/CSR.h:195-245
@@ -53,6 +54,20 @@ int ref_spmm(int which, const int* IA, const int* JA, const float* A, int nnzA,
   *IC = ic; *JC = jc; *C = c; *nnzC = nz;
   return 0;
 }
+
+// IC[m+1] <- C.rowPtr, fp[m+1] <- exclusive prefix of the per-row "footprints" the static scheduler balances
+// (static_omp_CSR_SpMM, nlibs/static_omp_csr_kernel.cc:106-130)
+void ref_footprints(const int* IA, const int* JA, const int* IB, const int* JB, int m, int n, int* IC, int* fp, int stride) {
+  int nnzC = 0;
+#pragma omp parallel
+  {
+    thread_data_t td(n);
+    dynamic_omp_CSR_IC_nnzC_footprints(IA, JA, IB, JB, m, n, td, IC, nnzC, fp, stride);
+  }
+}
+
+// ends[parts+1] <- arrayEqualPartition on an int prefix array (the footprint cut)
+void ref_equal_partition(int* prefix, int n, int parts, int* ends) { arrayEqualPartition(prefix, n, parts, ends); }
 
 // rowFlops[m+1] <- exclusive prefix of per-row product counts (long), as the reference leaves it
 void ref_row_flops_prefix(const int* IA, const int* JA, const int* IB, const int* JB,

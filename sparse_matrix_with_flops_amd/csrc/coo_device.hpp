@@ -285,19 +285,21 @@ extern "C" int hip_coo_to_csr(spgemm_handle* h, int rows, int cols, int nnz, con
 // rows with flops <= 1, the last bucket everything above 2^11.  Row flops come from the path's own K1 kernel.
 // ------------------------------------------------------------------------------------------------
 namespace coo {
-__global__ void k_pow2_hist(int m, const int* __restrict__ val, int* __restrict__ hist /*[SPGEMM_STATS_LEN]*/) {
-  __shared__ int sh[SPGEMM_STATS_LEN];
-  if (threadIdx.x < SPGEMM_STATS_LEN) sh[threadIdx.x] = 0;
+// val != nullptr: values themselves; otherwise differences of neighbours of `ptr` (row lengths of a CSR rowPtr)
+__global__ void k_pow2_hist(int m, const int* __restrict__ val, const int* __restrict__ ptr, int nb,
+                            int* __restrict__ hist /*[nb]*/) {
+  __shared__ int sh[32];
+  if (threadIdx.x < 32) sh[threadIdx.x] = 0;
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < m) {
-    const long long v = val[i];
-    int b = SPGEMM_STATS_LEN - 1;
-    for (int q = 0; q < SPGEMM_STATS_LEN - 1; ++q) if (v <= (1ll << q)) { b = q; break; }
+    const long long v = val ? (long long)val[i] : (long long)ptr[i + 1] - (long long)ptr[i];
+    int b = nb - 1;
+    for (int q = 0; q < nb - 1; ++q) if (v <= (1ll << q)) { b = q; break; }
     atomicAdd(&sh[b], 1);
   }
   __syncthreads();
-  if (threadIdx.x < SPGEMM_STATS_LEN && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+  if (threadIdx.x < nb && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
 }
 }  // namespace coo
 
@@ -317,9 +319,74 @@ extern "C" int hip_flopsStats(spgemm_handle* h, const int* dIA, const int* dJA, 
   int rc = hip_csr_row_flops(h, dIA, dJA, dIB, m, flops, nullptr);
   if (rc) return cleanup(rc);
   if (hipMemsetAsync(hist, 0, sizeof(int) * SPGEMM_STATS_LEN, h->stream) != hipSuccess) return cleanup(fail(SPGEMM_ERR_HIP, "memset failed"));
-  hipLaunchKernelGGL(coo::k_pow2_hist, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, m, flops, hist);
+  hipLaunchKernelGGL(coo::k_pow2_hist, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, m, flops, (const int*)nullptr,
+                     SPGEMM_STATS_LEN, hist);
   if (hipMemcpyAsync(stats, hist, sizeof(int) * SPGEMM_STATS_LEN, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
       hipStreamSynchronize(h->stream) != hipSuccess)
     return cleanup(fail(SPGEMM_ERR_HIP, "flops statistics failed: %s", hipGetErrorString(hipGetLastError())));
   return cleanup(SPGEMM_OK);
+}
+
+
+// vector<int> CSR::nnzStats() (nlibs/CSR.cc:241-248): 18 power-of-two buckets of the ROW LENGTHS of a device CSR
+extern "C" int hip_nnzStats(spgemm_handle* h, const int* dIA, int m, int stats[SPGEMM_NNZ_STATS_LEN]) {
+  if (!stats) return fail(SPGEMM_ERR_ARG, "stats is null");
+  for (int i = 0; i < SPGEMM_NNZ_STATS_LEN; ++i) stats[i] = 0;
+  if (m < 0 || !dIA) return fail(SPGEMM_ERR_ARG, "bad argument");
+  if (m == 0) return SPGEMM_OK;
+  if (!h) CHK(default_handle(&h));
+  HIPCHK(hipSetDevice(h->device));
+  int* hist = nullptr;
+  auto cleanup = [&](int rc) { pool().release(hist); return rc; };
+  if (pool().alloc((void**)&hist, sizeof(int) * SPGEMM_NNZ_STATS_LEN) != hipSuccess) return cleanup(fail(SPGEMM_ERR_HIP, "device allocation failed"));
+  if (hipMemsetAsync(hist, 0, sizeof(int) * SPGEMM_NNZ_STATS_LEN, h->stream) != hipSuccess) return cleanup(fail(SPGEMM_ERR_HIP, "memset failed"));
+  hipLaunchKernelGGL(coo::k_pow2_hist, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, m, (const int*)nullptr, dIA,
+                     SPGEMM_NNZ_STATS_LEN, hist);
+  if (hipMemcpyAsync(stats, hist, sizeof(int) * SPGEMM_NNZ_STATS_LEN, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+      hipStreamSynchronize(h->stream) != hipSuccess)
+    return cleanup(fail(SPGEMM_ERR_HIP, "row-length statistics failed: %s", hipGetErrorString(hipGetLastError())));
+  return cleanup(SPGEMM_OK);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-bin correctness report: resultsComparison / isPartialRawEqual (mindex2-cuda/nGpuSpMM.cc:85-240) compare the GPU
+// result hC with a CPU result rC bin by bin (rows of reference bin b sit at hqueue[hv[b]-1 .. hv[b+1]-1), flops.cu) so
+// that a wrong kernel shows up as "its" bin.  Host arrays in (this is a checking aid, not a device path); rows are
+// compared as sets of (column, value): row lengths, columns, values within `rel` relative (|x-y| <= rel*max(|x|,|y|)).
+// ------------------------------------------------------------------------------------------------
+extern "C" int hip_resultsComparison(int m, int n, const int* hIC, const int* hJC, const float* hC, const int* rIC,
+                                     const int* rJC, const float* rC, const int hv[SPGEMM_HV_LEN], int hv_len,
+                                     const int* hqueue, double rel, spgemm_bin_report report[SPGEMM_HV_LEN - 1]) {
+  if (!hIC || !rIC || !hv || !hqueue || !report) return fail(SPGEMM_ERR_ARG, "null argument");
+  if (m < 0 || n < 0 || hv_len < 2 || hv_len > SPGEMM_HV_LEN) return fail(SPGEMM_ERR_ARG, "bad size");
+  std::vector<float> val((size_t)std::max(n, 1), 0.f);
+  std::vector<int> stamp((size_t)std::max(n, 1), -1);
+  for (int b = 0; b < SPGEMM_HV_LEN - 1; ++b) {
+    spgemm_bin_report& R = report[b];
+    R.rows = 0; R.rows_differ = 0; R.first_bad_row = -1; R.max_rel_err = 0.0;
+    if (b + 1 >= hv_len) continue;
+    const int lo = std::max(hv[b] - 1, 0), hi = hv[b + 1] - 1;      // element 0 of the (m+1)-long bin array is a dummy
+    for (int q = lo; q < hi; ++q) {
+      const int row = hqueue[q];
+      if ((unsigned)row >= (unsigned)m) return fail(SPGEMM_ERR_INPUT, "queue entry %d is not a row", row);
+      ++R.rows;
+      bool bad = (hIC[row + 1] - hIC[row]) != (rIC[row + 1] - rIC[row]);
+      for (int p = rIC[row]; p < rIC[row + 1]; ++p) {
+        if ((unsigned)rJC[p] >= (unsigned)n) return fail(SPGEMM_ERR_INPUT, "column out of range in rC");
+        stamp[rJC[p]] = row; val[rJC[p]] = rC[p];
+      }
+      for (int p = hIC[row]; p < hIC[row + 1]; ++p) {
+        const int c = hJC[p];
+        if ((unsigned)c >= (unsigned)n) return fail(SPGEMM_ERR_INPUT, "column out of range in hC");
+        if (stamp[c] != row) { bad = true; continue; }
+        const double x = hC[p], y = val[c];
+        const double den = std::max(std::fabs(x), std::fabs(y));
+        const double e = den > 0.0 ? std::fabs(x - y) / den : 0.0;
+        if (e > R.max_rel_err) R.max_rel_err = e;
+        if (e > rel) bad = true;
+      }
+      if (bad) { ++R.rows_differ; if (R.first_bad_row < 0) R.first_bad_row = row; }
+    }
+  }
+  return SPGEMM_OK;
 }

@@ -208,3 +208,42 @@ void gpuRmclIter(const int maxIter, const CSR Mgt, CSR& Mt) {
   Mt.dispose();                                   // nlibs/gpus/gpu_csr_kernel.cu:302-303: old arrays freed, new malloc()ed
   Mt.init(oA, oJ, oI, Mgt.rows, Mgt.cols, on);
 }
+
+
+std::vector<int> CSR::nnzStats() const {
+  std::vector<int> stats(SPGEMM_NNZ_STATS_LEN, 0);
+  for (int r = 0; r < rows; ++r) {
+    const long len = rowPtr[r + 1] - rowPtr[r];
+    int b = SPGEMM_NNZ_STATS_LEN - 1;
+    for (int q = 0; q < SPGEMM_NNZ_STATS_LEN - 1; ++q) if (len <= (1l << q)) { b = q; break; }
+    ++stats[b];
+  }
+  return stats;
+}
+
+std::vector<int> CSR::gpuNnzStats() const {
+  std::vector<int> stats(SPGEMM_NNZ_STATS_LEN, 0);
+  if (hip_nnzStats(NULL, rowPtr, rows, stats.data())) { printf("%s\n", spgemm_hip_last_error()); exit(EXIT_FAILURE); }
+  return stats;
+}
+
+bool resultsComparison(const CSR& hC, const CSR& rC, const std::vector<int>& hv, const int* hqueue, double rel) {
+  static const char* const kBinNames[SPGEMM_HV_LEN - 1] = {"(bin 0, unused)", "0 products", "1 product", "2-4", "5-16",
+                                                           "17-64", "65-512", ">512"};
+  if (hC.rows != rC.rows || hC.cols != rC.cols) { printf("resultsComparison: shapes differ\n"); return false; }
+  int hvv[SPGEMM_HV_LEN];
+  const int len = (int)std::min<size_t>(hv.size(), SPGEMM_HV_LEN);
+  for (int i = 0; i < SPGEMM_HV_LEN; ++i) hvv[i] = i < len ? hv[i] : (len ? hv[len - 1] : 0);
+  spgemm_bin_report rep[SPGEMM_HV_LEN - 1];
+  hip_or_die(hip_resultsComparison(hC.rows, hC.cols, hC.rowPtr, hC.colInd, hC.values, rC.rowPtr, rC.colInd, rC.values, hvv, len,
+                                   hqueue, rel, rep), "resultsComparison");
+  bool same = hC.nnz == rC.nnz;
+  printf("hC compare with rC: nnz %d vs %d\n", hC.nnz, rC.nnz);
+  for (int b = 1; b + 1 < len; ++b) {
+    printf("Checking %-12s rows= %d differ= %d first= %d max_rel_err= %.3e\n", kBinNames[b], rep[b].rows, rep[b].rows_differ,
+           rep[b].first_bad_row, rep[b].max_rel_err);
+    same = same && rep[b].rows_differ == 0;
+  }
+  std::printf("%s\n", same ? "Same" : "Diffs");
+  return same;
+}

@@ -5,6 +5,7 @@
 // here computes a product on the CPU.
 #ifndef SMF_CSR_H_
 #define SMF_CSR_H_
+#include <vector>
 #include "tools/macro.h"
 
 struct CSR {
@@ -43,5 +44,10 @@ struct CSR {
 
   // 2 * (number of intermediate products), the reference's original getSpMMFlops (nlibs/cpu_csr_kernel.cc:39-56)
   long long spMMFlops(const CSR& B) const;
+
+  // 18 power-of-two buckets of the row lengths (nlibs/CSR.cc:241-248); host CSR: counted here, device CSR
+  // (after toGpuCSR): hip_nnzStats
+  std::vector<int> nnzStats() const;
+  std::vector<int> gpuNnzStats() const;
 };
 #endif

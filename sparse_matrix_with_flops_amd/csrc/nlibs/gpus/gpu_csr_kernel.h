@@ -16,6 +16,12 @@ CSR sgpuSpMMWrapper(const CSR& dA, const CSR& dB, int* drowIds, const std::vecto
 CSR scudaSpMM(const CSR& hA, const CSR& hB);
 void gpuRmclIter(const int maxIter, const CSR Mgt, CSR& Mt);
 
+// bool resultsComparison(CSR& hC, CSR& rC, const vector<int>& hv, const int* hqueue) (mindex2-cuda/nGpuSpMM.cc:138-240):
+// hC (result under test) against rC (reference result), whole matrix first, then bin by bin; prints one line per bin
+// (rows compared / rows that differ / first such row / largest relative value error) and returns true iff nothing
+// differs.  hv and hqueue (HOST copy of the row queue) are the outputs of gpuFlopsClassify.
+bool resultsComparison(const CSR& hC, const CSR& rC, const std::vector<int>& hv, const int* hqueue, double rel = 1e-6);
+
 // raw arrays, the signature every CPU kernel of the reference has
 void hip_CSR_SpMM(const int IA[], const int JA[], const QValue A[], const int nnzA,
                   const int IB[], const int JB[], const QValue B[], const int nnzB,

@@ -6,6 +6,7 @@
 #include "../../include/spgemm_hip.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>

@@ -45,6 +45,19 @@ def equal_partition64(prefix, parts):
     return ends
 
 
+def footprint_prefix(row_flops, row_counts, row_nnzA):
+    """The reference's alternative load measure (static scheduler, nlibs/static_omp_csr_kernel.cc:28-62
+    footPrintsCrowiCount): per row of C (flops + nnz(C row) + 32 + nnz(A row)) >> 1 -- work of the numeric pass plus
+    what the row writes -- 0 for an empty A row.  Returns the exclusive prefix [m+1] (int64), ready for
+    equal_partition64 (the reference cuts it with arrayEqualPartition, the int32 twin of the same rule)."""
+    fl = np.asarray(row_flops, dtype=np.int64)
+    na = np.asarray(row_nnzA, dtype=np.int64)
+    fp = np.where(na > 0, (fl + np.asarray(row_counts, dtype=np.int64) + 32 + na) >> 1, 0)
+    out = np.zeros(len(fl) + 1, dtype=np.int64)
+    np.cumsum(fp, out=out[1:])
+    return out
+
+
 def _ptr(t):
     return t.data_ptr() if t.numel() else 0
 
@@ -182,11 +195,21 @@ class ShardedSpGEMM:
         prefix = np.zeros(self.m + 1, dtype=np.int64)
         np.cumsum(flops, out=prefix[1:])
         self.prefix = prefix
-        self.ends = equal_partition64(prefix, self.world)
+        rpA = np.asarray(rpA)
+        self.partition = partition
+        if partition == "footprint":
+            # one symbolic pass over the whole A (every rank, once): row lengths of C -> the reference's footprint measure
+            IC_all, _ = engine.symbolic(fullA, self.B)
+            counts = np.diff(IC_all.cpu().numpy().astype(np.int64))
+            self.cut_prefix = footprint_prefix(flops, counts, np.diff(rpA))
+        elif partition == "flops":
+            self.cut_prefix = prefix
+        else:
+            raise ValueError(f"unknown partition {partition!r}")
+        self.ends = equal_partition64(self.cut_prefix, self.world)
         r0, r1 = int(self.ends[self.rank]), int(self.ends[self.rank + 1])
         self.r0, self.r1 = r0, r1
         self.local_flops = int(prefix[r1] - prefix[r0])
-        rpA = np.asarray(rpA)
         ciA, vA = np.asarray(ciA), np.asarray(vA)
         lo, hi = int(rpA[r0]), int(rpA[r1])
         self.A_local = make_matrix(engine, (rpA[r0:r1 + 1] - lo).astype(np.int32), ciA[lo:hi], vA[lo:hi], r1 - r0, self.k)
@@ -195,7 +218,7 @@ class ShardedSpGEMM:
         self.sub_ends = []                                   # per rank: chunks+1 global row indices
         for r in range(self.world):
             a0, a1 = int(self.ends[r]), int(self.ends[r + 1])
-            cut = equal_partition64(prefix[a0:a1 + 1] - prefix[a0], self.chunks) + a0 if a1 > a0 else \
+            cut = equal_partition64(self.cut_prefix[a0:a1 + 1] - self.cut_prefix[a0], self.chunks) + a0 if a1 > a0 else \
                 np.full(self.chunks + 1, a0, dtype=np.int64)
             self.sub_ends.append(cut)
         self.A_sub = []

@@ -35,12 +35,16 @@ EXPORTS = [
     "hip_gpuFlopsClassify", "hip_sgpuSpMM", "hip_csr_sort_rows", "spgemm_hip_selftest",
     "hip_spgemm_symbolic", "hip_spgemm_numeric", "hip_csr_row_flops", "spgemm_hip_kernel_name",
     "hip_rmcl_prune", "hip_gpuRmclIter", "hip_coo_to_csr", "hip_flopsStats", "spgemm_hip_set_kernel_timing",
-    "hip_rmcl_prune_n", "spgemm_hip_pool_cached_bytes",
+    "hip_rmcl_prune_n", "spgemm_hip_pool_cached_bytes", "hip_nnzStats", "hip_resultsComparison",
 ]
 
 
 class SpgemmError(RuntimeError):
     pass
+
+
+class BinReport(C.Structure):
+    _fields_ = [("rows", C.c_int), ("rows_differ", C.c_int), ("first_bad_row", C.c_int), ("max_rel_err", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -105,6 +109,9 @@ def lib():
         L.hip_rmcl_prune_n.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + \
             [C.POINTER(C.c_void_p)] * 3 + [_I]
         L.spgemm_hip_pool_cached_bytes.argtypes = [C.c_int, C.POINTER(C.c_size_t)]
+        L.hip_nnzStats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.hip_resultsComparison.argtypes = [C.c_int, C.c_int, _I, _I, _F, _I, _I, _F, _I, C.c_int, _I, C.c_double,
+                                            C.POINTER(BinReport)]
         L.hip_gpuRmclIter.argtypes = [C.c_int, C.c_int, C.c_int, _I, _I, _F, C.c_int, _I, _I, _F, C.c_int,
                                       C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I]
         L.hip_csr_sort_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -338,6 +345,29 @@ def flopsStats(dA, dB, handle=None):
     _check(lib().hip_flopsStats(handle.ptr if handle else None, C.c_void_p(dA.rowPtr), C.c_void_p(dA.colInd),
                                 C.c_void_p(dB.rowPtr), dA.rows, out), "hip_flopsStats")
     return [int(x) for x in out]
+
+
+def nnzStats(dA, handle=None):
+    """CSR::nnzStats (nlibs/CSR.cc:241-248) of a device CSR: 18 power-of-two buckets of the row lengths."""
+    out = (C.c_int * 18)()
+    _check(lib().hip_nnzStats(handle.ptr if handle else None, C.c_void_p(dA.rowPtr), int(dA.rows), out), "hip_nnzStats")
+    return [int(x) for x in out]
+
+
+def resultsComparison(hC, rC, hv, hqueue, rel=1e-6):
+    """resultsComparison / isPartialRawEqual (mindex2-cuda/nGpuSpMM.cc:85-240) on host CSRs: per reference bin
+    {rows, rows_differ, first_bad_row, max_rel_err}.  hv/hqueue: outputs of gpuFlopsClassify (queue on the host)."""
+    rep = (BinReport * (HV_LEN - 1))()
+    hvv = (C.c_int * HV_LEN)(*([int(x) for x in hv] + [int(hv[-1])] * (HV_LEN - len(hv))))
+    q = np.ascontiguousarray(hqueue, dtype=np.int32)
+    a = [np.ascontiguousarray(x, dtype=t) for x, t in ((hC.rowPtr, np.int32), (hC.colInd, np.int32), (hC.values, np.float32),
+                                                        (rC.rowPtr, np.int32), (rC.colInd, np.int32), (rC.values, np.float32))]
+    p = lambda arr, ty: arr.ctypes.data_as(ty)
+    _check(lib().hip_resultsComparison(int(hC.rows), int(hC.cols), p(a[0], _I), p(a[1], _I), p(a[2], _F), p(a[3], _I),
+                                       p(a[4], _I), p(a[5], _F), hvv, len(hv), p(q, _I), float(rel), rep),
+           "hip_resultsComparison")
+    return [{"rows": r.rows, "rows_differ": r.rows_differ, "first_bad_row": r.first_bad_row, "max_rel_err": r.max_rel_err}
+            for r in rep]
 
 
 def coo_to_csr_raw(handle, rows, cols, nnz, dRow, dCol, dVal, flags):

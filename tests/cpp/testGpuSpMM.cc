@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "COO.h"
 #include "CSR.h"
@@ -64,10 +65,19 @@ int main(int argc, char* argv[]) {
 
   CSR dA = A.toGpuCSR(), dB = B.toGpuCSR();
   outputStats(gpuFlopsStats(dA, dB));            // tools/stats.cc report: rows by power-of-two flop class
+  outputStats(dA.gpuNnzStats());                 // CSR::nnzStats of the input: rows by power-of-two length class
   CSR dC = gpuSpMMWrapper(dA, dB);
-  dA.deviceDispose(); dB.deviceDispose();
   CSR hC = dC.toCpuCSR();
   dC.deviceDispose();
+  {                                               // per-bin report, like resultsComparison (nGpuSpMM.cc:138-240)
+    int *drowIds = 0, *dflops = 0;
+    std::vector<int> hv = gpuFlopsClassify(dA, dB, &drowIds, &dflops);
+    std::vector<int> hqueue((size_t)A.rows + 1);
+    if (A.rows) spgemm_hip_memcpy_d2h(hqueue.data(), drowIds, sizeof(int) * (size_t)A.rows);
+    spgemm_hip_free(drowIds); spgemm_hip_free(dflops);
+    bad += report("resultsComparison per bin", resultsComparison(hC, want, hv, hqueue.data()));
+  }
+  dA.deviceDispose(); dB.deviceDispose();
   hC.makeOrdered();
   bad += report("gpuSpMMWrapper isEqual", hC.isEqual(want));
   bad += report("gpuSpMMWrapper parity", hC.isParityEqual(want));

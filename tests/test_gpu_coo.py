@@ -95,3 +95,41 @@ def test_flops_stats_match_oracle(m, seed):
     got = hs.flopsStats(dA, dA)
     dA.deviceDispose()
     assert got == [int(x) for x in po.flops_stats(A, A)] and sum(got) == m
+
+
+def test_row_length_stats_and_per_bin_report():
+    """SURVEY.md §8f rank 4: CSR::nnzStats on the device (18 power-of-two buckets of the row lengths) and the per-bin
+    GPU-vs-CPU report of resultsComparison: clean on a correct result, and it names the right bin and row when one
+    entry of the result is corrupted."""
+    A = synth_csr(20000, 33, 2)
+    hA = hs.CSR.from_arrays(A.rowPtr, A.colInd, A.values, A.rows, A.cols)
+    dA = hA.toGpuCSR()
+    got = hs.nnzStats(dA)
+    lens = np.diff(A.rowPtr).astype(np.int64)
+    want = np.zeros(18, dtype=np.int64)
+    for b in range(18):
+        lo = 0 if b == 0 else (1 << (b - 1)) + 1
+        want[b] = np.sum((lens >= (lo if b else -1)) & (lens <= (1 << b))) if b < 17 else np.sum(lens > (1 << 16))
+    want[0] = np.sum(lens <= 1)
+    assert got == [int(x) for x in want] and sum(got) == A.rows
+    # per-bin report
+    hv, hv_len, ids, fl, tot = hs.gpuFlopsClassify(dA, dA)
+    queue = hs.d2h(ids, A.rows, np.int32)
+    dC = hs.gpuSpMMWrapper(dA, dA)
+    hC = dC.toCpuCSR()
+    dC.deviceDispose()
+    ref = po.omp_spmm(A, A)
+    rep = hs.resultsComparison(hC, ref, hv[:hv_len], queue)
+    flops = po.row_flops(A, A)
+    assert sum(r["rows"] for r in rep) == A.rows and all(r["rows_differ"] == 0 for r in rep)
+    assert max(r["max_rel_err"] for r in rep) <= 1e-6
+    assert rep[6]["rows"] == int(np.sum((flops > 64) & (flops <= 512)))          # reference bin "65-512 products"
+    bad_row = int(np.nonzero((flops > 64) & (flops <= 512))[0][5])
+    vals = hC.values.copy()
+    vals[hC.rowPtr[bad_row]] *= 1.01
+    broken = po.CSRHost(hC.rowPtr, hC.colInd, vals, hC.rows, hC.cols)
+    rep2 = hs.resultsComparison(broken, ref, hv[:hv_len], queue)
+    assert [r["rows_differ"] for r in rep2] == [0, 0, 0, 0, 0, 0, 1, 0] and rep2[6]["first_bad_row"] == bad_row
+    for p in (ids, fl):
+        hs.dev_free(p)
+    dA.deviceDispose()

@@ -30,7 +30,7 @@ def _graph(m, seed):
     return po.rmcl_init(A.rows, A.cols, A.colInd, ri, np.ones_like(A.values))
 
 
-def _worker(rank, world, port, kind, m, seed, q, chunks=1):
+def _worker(rank, world, port, kind, m, seed, q, chunks=1, partition="flops"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from sparse_matrix_with_flops_amd.dist import HipEngine, ShardedRMCL, ShardedSpGEMM
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,7 +38,7 @@ def _worker(rank, world, port, kind, m, seed, q, chunks=1):
         eng = HipEngine(0, handles=chunks)
         if kind == "spgemm":
             A = synth_csr(m, seed, 2)
-            job = ShardedSpGEMM(eng, (A.rowPtr, A.colInd, A.values, A.rows, A.cols), None, chunks=chunks)
+            job = ShardedSpGEMM(eng, (A.rowPtr, A.colInd, A.values, A.rows, A.cols), None, chunks=chunks, partition=partition)
             rp, jc, cv = job.step()
             rp, jc, cv = job.step()                   # again: gathered buffers and handles are reused
             torch.cuda.synchronize()
@@ -54,11 +54,11 @@ def _worker(rank, world, port, kind, m, seed, q, chunks=1):
         dist.destroy_process_group()
 
 
-def _run(kind, m, seed, world=2, chunks=1):
+def _run(kind, m, seed, world=2, chunks=1, partition="flops"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, m, seed, q, chunks)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, m, seed, q, chunks, partition)) for r in range(world)]
     for p in procs:
         p.start()
     outs = []
@@ -90,6 +90,21 @@ def test_sharded_spgemm_two_ranks_hip_engine(chunks):
     for rank, rp, jc, cv, ends in outs:
         assert np.array_equal(ends, po.equal_partition64(prefix, 2))                # arrayEqualPartition64 on device flops
         assert_parity(po.CSRHost(rp, jc, cv, m, m), want, what=f"rank {rank}")      # every rank holds the whole C
+
+
+def test_sharded_spgemm_footprint_partition():
+    """The reference's other load measure as the cut (static scheduler footprints, static_omp_csr_kernel.cc:28-95):
+    flops from hip_csr_row_flops + row lengths of C from a device symbolic pass must give the partition the oracle's
+    restatement (pinned to the real reference in tests/test_oracle_vs_ref.py) gives; the product is unchanged."""
+    from sparse_matrix_with_flops_amd.dist import equal_partition64
+    m, seed = 30000, 21
+    outs = _run("spgemm", m, seed, partition="footprint")
+    A = synth_csr(m, seed, 2)
+    want = po.omp_spmm(A, A)
+    cut = equal_partition64(po.footprints(A, A, np.diff(want.rowPtr)), 2)
+    for rank, rp, jc, cv, ends in outs:
+        assert np.array_equal(ends, cut)
+        assert_parity(po.CSRHost(rp, jc, cv, m, m), want, what=f"rank {rank}")
 
 
 def test_sharded_rmcl_two_ranks_hip_engine():

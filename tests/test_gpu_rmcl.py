@@ -131,3 +131,12 @@ def test_cpp_mirror_runs_the_reference_test_protocol():
         out = subprocess.run([exe, os.path.join(DATA, name)] + extra, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "Differs" not in out.stdout and "Same" in out.stdout
+    # nrmcl with the reference's flags (process_args.cc:12-27): --input/-i --maxIters/-m --stride --rmclOptions/-r
+    exe = os.path.join(ROOT, "tests", "cpp", "nrmcl.x")
+    for args in (["--input", os.path.join(DATA, "t2.snap"), "--maxIters", "3", "--stride", "128", "--rmclOptions", "GPU"],
+                 ["-i", os.path.join(DATA, "own_graph.snap"), "-m", "2", "-r", "GPU", "--stats"]):
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "rmclOption= GPU" in out.stdout and "Same" in out.stdout and "Diffs" not in out.stdout
+        if "--stats" in args:
+            assert "Total sum =" in out.stdout

@@ -61,3 +61,20 @@ def test_threshold_random():
     for _ in range(2000):
         avg, mx = np.float32(rng.random()), np.float32(rng.random())
         assert L.oracle_compute_threshold(avg, mx) == R.ref_compute_threshold(avg, mx)
+
+
+def test_footprints_match_the_reference_static_scheduler():
+    """oracle footprints() (and the product's dist.footprint_prefix fed with oracle flops/counts) against
+    dynamic_omp_CSR_IC_nnzC_footprints + arrayEqualPartition of the real reference."""
+    from sparse_matrix_with_flops_amd.dist import equal_partition64, footprint_prefix
+    for m, seed in ((300, 3), (5000, 7), (20000, 9)):
+        A = synth_csr(m, seed, 2)
+        ic, fp = po.ref_footprints(A, A)
+        want = po.omp_spmm(A, A)
+        assert np.array_equal(ic, want.rowPtr)
+        mine = po.footprints(A, A, np.diff(want.rowPtr))
+        assert np.array_equal(mine, fp.astype(np.int64))
+        prod = footprint_prefix(po.row_flops(A, A), np.diff(want.rowPtr), np.diff(A.rowPtr))
+        assert np.array_equal(prod, mine)
+        for parts in (2, 8):
+            assert np.array_equal(equal_partition64(prod, parts), po.ref_equal_partition(fp, parts).astype(np.int64))
