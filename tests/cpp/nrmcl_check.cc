@@ -16,14 +16,13 @@ int main(int argc, char* argv[]) {
   coo.readSNAPFile(options.inputFileName);
   CSR M0 = rmclInit(coo);
   coo.dispose();
-  int *oI, *oJ, onnz;
-  float* oV;
-  oracle_rmcl_iters(options.maxIters, M0.rows, M0.cols, M0.rowPtr, M0.colInd, M0.values, M0.nnz, &oI, &oJ, &oV, &onnz);
-  CSR want(oV, oJ, oI, M0.rows, M0.cols, onnz);
+  CSR Mg = M0.deepCopy();                        // the checker consumes the Mt arrays it is given and returns new ones
+  oracle_rmcl_iters(options.maxIters, Mg.rows, Mg.cols, Mg.rowPtr, Mg.colInd, Mg.values, Mg.nnz, &M0.rowPtr, &M0.colInd,
+                    &M0.values, &M0.nnz);
   Mt.makeOrdered();
-  want.makeOrdered();
-  const bool isSame = Mt.isEqual(want);
+  M0.makeOrdered();
+  const bool isSame = Mt.isEqual(M0);
   std::cout << (isSame ? "Same\n" : "Diffs\n");
-  want.dispose(); M0.dispose(); Mt.dispose();
+  Mg.dispose(); M0.dispose(); Mt.dispose();
   return isSame ? 0 : 1;
 }
