@@ -47,9 +47,9 @@ def bin_of(f):
 
 # which bins each kernel covers, and whether it is a symbolic (keys only) or numeric launch
 KERNEL_BINS = {
-    "k_sym_small<4,32>": ((2, 3), "sym"), "k_sym_g16": ((4,), "sym"), "k_sym_hash<1,1024>": ((5,), "sym"),
+    "k_sym_g16<32,1>": ((2, 3), "sym"), "k_sym_g16": ((4,), "sym"), "k_sym_hash<1,1024>": ((5,), "sym"),
     "k_sym_hash<4,4096>": ((6,), "sym"), "k_sym_hash<8,8192>": ((7,), "sym"), "k_sym_big": ((8,), "sym"),
-    "k_num_small<4,32>": ((1, 2, 3), "num"), "k_num_g16": ((4,), "num"), "k_num_hash<1,1024>": ((5,), "num"),
+    "k_num_g16<32,1>": ((1, 2, 3), "num"), "k_num_g16": ((4,), "num"), "k_num_hash<1,1024>": ((5,), "num"),
     "k_num_hash<4,4096>": ((6,), "num"), "k_num_hash<8,8192>": ((7,), "num"), "k_num_big": ((8,), "num"),
     "k_num_bighash": ((8,), "num"),
 }

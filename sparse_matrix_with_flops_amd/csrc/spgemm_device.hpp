@@ -672,6 +672,7 @@ template <int U, bool NEED_VAL, class F>
 __device__ __forceinline__ void g16_walk(G16Stage& st, int gl, int as, int ae, const int2* __restrict__ SBL,
                                          const float* __restrict__ VA,
                                          const int* __restrict__ JB, const float* __restrict__ VB, F&& f) {
+  int rowBase = 0;                                  // products of the chunks before this one
   for (int chunk = as; chunk < ae; chunk += 16) {
     const int ap = chunk + gl;
     int len = 0, bs = 0;
@@ -715,14 +716,15 @@ __device__ __forceinline__ void g16_walk(G16Stage& st, int gl, int as, int ae, c
 #pragma unroll
       for (int u = 0; u < U; ++u) val[u] = av[u] * vb[u];
 #pragma unroll
-      for (int u = 0; u < U; ++u) f(act[u], col[u], val[u]);
+      for (int u = 0; u < U; ++u) f(act[u], col[u], val[u], rowBase + (r0 + u) * 16 + gl);
     }
+    rowBase += T;
     wave_lds_sync();
   }
 }
 
 template <int TBL, int U>
-__global__ __launch_bounds__(256) void k_sym_g16(const int* __restrict__ binPtr, int bin,
+__global__ __launch_bounds__(256) void k_sym_g16(const int* __restrict__ binPtr, int bin, int binHi,
                                                   const int* __restrict__ rowIds,
                                                   const int* __restrict__ IA, const int2* __restrict__ SBL,
                                                   const int* __restrict__ JB,
@@ -731,7 +733,7 @@ __global__ __launch_bounds__(256) void k_sym_g16(const int* __restrict__ binPtr,
   __shared__ int keys[16][TBL];
   __shared__ G16Stage st[16];
   const int tid = threadIdx.x, g = tid >> 4, gl = tid & 15;
-  const int first = binPtr[bin], count = binPtr[bin + 1] - first;
+  const int first = binPtr[bin], count = binPtr[binHi] - first;
   const int iters = (count + 15) / 16;
   // XCD-contiguous schedule: the blocks that share an XCD (blockIdx % 8, guide "Workgroup dispatch") walk ONE contiguous
   // eighth of the bin, so that the B rows its A rows have in common are fetched into that XCD's L2 once, not into all eight
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(256) void k_sym_g16(const int* __restrict__ binPtr,
     wave_lds_sync();
     int mine = 0;
     if (live) {
-      g16_walk<U, false>(st[g], gl, IA[row], IA[row + 1], SBL, nullptr, JB, nullptr, [&](bool active, int col, float) {
+      g16_walk<U, false>(st[g], gl, IA[row], IA[row + 1], SBL, nullptr, JB, nullptr, [&](bool active, int col, float, int) {
         if (active) {
           bool isnew;
           hash_insert(keys[g], size, shift, col, &isnew, err);
@@ -762,18 +764,19 @@ __global__ __launch_bounds__(256) void k_sym_g16(const int* __restrict__ binPtr,
 }
 
 template <int TBL, int U>
-__global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr, int bin,
+__global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr, int bin, int binHi,
                                                   const int* __restrict__ rowIds,
                                                   const int* __restrict__ IA, const int2* __restrict__ SBL,
                                                   const float* __restrict__ VA,
                                                   const int* __restrict__ JB,
                                                   const float* __restrict__ VB,
                                                   const int* __restrict__ IC, int* __restrict__ JC,
-                                                  float* __restrict__ C, int* __restrict__ err) {
+                                                  float* __restrict__ C, int* __restrict__ err,
+                                                  const int* __restrict__ rowFlops) {
   __shared__ slot_t tab[16][TBL];              // (column, value) pairs
   __shared__ G16Stage st[16];
   const int tid = threadIdx.x, g = tid >> 4, gl = tid & 15;
-  const int first = binPtr[bin], count = binPtr[bin + 1] - first;
+  const int first = binPtr[bin], count = binPtr[binHi] - first;
   const int iters = (count + 15) / 16;
   // XCD-contiguous schedule: the blocks that share an XCD (blockIdx % 8, guide "Workgroup dispatch") walk ONE contiguous
   // eighth of the bin, so that the B rows its A rows have in common are fetched into that XCD's L2 once, not into all eight
@@ -784,12 +787,24 @@ __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr,
     const int row = live ? rowIds[first + q] : 0;
     const int off = live ? IC[row] : 0;
     const int want = live ? IC[row + 1] - off : 0;
+    // rows whose products all hit different columns (want == flops: 93-99 % of the rows this small on a power-law
+    // matrix) are EXPANDED: products go straight to their position in the row, no table, no compaction.  The four
+    // rows of a wave take the same path (wave-uniform control flow).
+    const bool hashRow = live && want != rowFlops[row];
+    if (ballot64(hashRow) == 0ull) {
+      if (live) {
+        g16_walk<U, true>(st[g], gl, IA[row], IA[row + 1], SBL, VA, JB, VB, [&](bool active, int col, float v, int pos) {
+          if (active && (unsigned)pos < (unsigned)want) { JC[off + pos] = col; C[off + pos] = v; }
+        });
+      }
+      continue;
+    }
     const int size = table_size(want, 16, TBL);
     const int shift = 32 - log2_pow2(size);
     for (int i = gl; i < size; i += 16) tab[g][i] = EMPTY_SLOT;
     wave_lds_sync();
     if (live) {
-      g16_walk<U, true>(st[g], gl, IA[row], IA[row + 1], SBL, VA, JB, VB, [&](bool active, int col, float v) {
+      g16_walk<U, true>(st[g], gl, IA[row], IA[row + 1], SBL, VA, JB, VB, [&](bool active, int col, float v, int) {
         if (active) hash_accum(tab[g], size, shift, col, v, err);
       });
     }
@@ -897,7 +912,7 @@ __device__ __forceinline__ GroupLanes stage_group(unsigned long long* marks, cha
 template <int U, bool NEED_VAL, int RS, class F>
 __device__ __forceinline__ void short_trip(const char* rec, int T, int ns, int r0, const unsigned long long (&W)[U],
                                            const int (&base)[U], const int* __restrict__ JB,
-                                           const float* __restrict__ VB, F&& f) {
+                                           const float* __restrict__ VB, F&& f, int p0row = -1) {
   const int lane = lane_id();
   int col[U];
   float av[U], vb[U], val[U];
@@ -921,8 +936,8 @@ __device__ __forceinline__ void short_trip(const char* rec, int T, int ns, int r
   __builtin_amdgcn_sched_barrier(0);                     // all 2U gathers are issued before the first of them is waited for
 #pragma unroll
   for (int u = 0; u < U; ++u) val[u] = av[u] * vb[u];
-  f(act, col, val);
-}
+  f(act, col, val, p0row);                              // p0row: index of the trip's first product in the row's own
+}                                                        // numbering (wave-per-row walk), -1 where there is none
 
 // 64*U consecutive products [s0, s0 + 64U) of one long B row: base, length and A value are wave-uniform
 template <int U, bool NEED_VAL, class F>
@@ -943,7 +958,7 @@ __device__ __forceinline__ void long_trip(int kb, int kl, float ka, int s0, cons
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int u = 0; u < U; ++u) val[u] = ka * vb[u];
-  f(act, col, val);
+  f(act, col, val, -1);
 }
 
 // wave-uniform R in 1..8 -> compile-time round count (5 runs as 6, 7 as 8): a trip costs what its rounds cost
@@ -969,6 +984,7 @@ for_each_product(WalkStage1& st, int as, int ae, const int2* __restrict__ SBL, c
                  const int* __restrict__ JB, const float* __restrict__ VB, F&& f,
                  PreA pre = PreA{0, 0, 0.f, false}, int* err = nullptr) {
   const int lane = lane_id();
+  int rowBase = 0;                                     // products of the groups before this one
   for (int gb = as; gb < ae; gb += WAVE) {
     const GroupLanes g = stage_group<NEED_VAL, 8, 0x40000000>(st.marks, reinterpret_cast<char*>(st.rec), gb + lane, ae, SBL, VA,
                                                               gb == as ? pre : PreA{0, 0, 0.f, false});
@@ -990,9 +1006,10 @@ for_each_product(WalkStage1& st, int as, int ae, const int2* __restrict__ SBL, c
                  ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mhi, r) << 32);
           base[u] = __builtin_amdgcn_readlane(g.pexcl, r);
         }
-        short_trip<R, NEED_VAL, 8>(reinterpret_cast<const char*>(st.rec), g.T, g.ns, r0, W, base, JB, VB, f);
+        short_trip<R, NEED_VAL, 8>(reinterpret_cast<const char*>(st.rec), g.T, g.ns, r0, W, base, JB, VB, f, rowBase + r0 * WAVE);
       });
     }
+    rowBase += g.T;
   }
 }
 
@@ -1085,16 +1102,20 @@ __device__ __forceinline__ int next_row(int* ctr, int* slot) { return next_row<1
 
 // per-row metadata, fetched one row ahead of use so that the dependent rowIds -> IA/IC loads of the
 // next row overlap the current row's work
-struct RowMeta { int row, as, ae, x0, x1; };
+struct RowMeta { int row, as, ae, x0, x1, x2; };
 
 __device__ __forceinline__ RowMeta load_meta_sym(const int* rows, int q, int count, const int* IA, const int* rowFlops) {
-  RowMeta mtd{0, 0, 0, 0, 0};
+  RowMeta mtd{0, 0, 0, 0, 0, 0};
   if (q < count) { mtd.row = rows[q]; mtd.as = IA[mtd.row]; mtd.ae = IA[mtd.row + 1]; mtd.x0 = rowFlops[mtd.row]; }
   return mtd;
 }
-__device__ __forceinline__ RowMeta load_meta_num(const int* rows, int q, int count, const int* IA, const int* IC) {
-  RowMeta mtd{0, 0, 0, 0, 0};
-  if (q < count) { mtd.row = rows[q]; mtd.as = IA[mtd.row]; mtd.ae = IA[mtd.row + 1]; mtd.x0 = IC[mtd.row]; mtd.x1 = IC[mtd.row + 1]; }
+__device__ __forceinline__ RowMeta load_meta_num(const int* rows, int q, int count, const int* IA, const int* IC,
+                                                 const int* rowFlops = nullptr) {
+  RowMeta mtd{0, 0, 0, 0, 0, 0};
+  if (q < count) {
+    mtd.row = rows[q]; mtd.as = IA[mtd.row]; mtd.ae = IA[mtd.row + 1]; mtd.x0 = IC[mtd.row]; mtd.x1 = IC[mtd.row + 1];
+    if (rowFlops) mtd.x2 = rowFlops[mtd.row];
+  }
   return mtd;
 }
 
@@ -1134,7 +1155,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ 
   int q = NW > 1 ? next_row<QB>(qctr, &qslot, -1) : (int)(blockIdx.x >> 3);
   RowMeta cur = load_meta_sym(rows, q, count, IA, rowFlops);
   // NW == 1: two rows of metadata and one row of A entries are in flight ahead of the row being processed
-  RowMeta nxt = NW == 1 ? load_meta_sym(rows, q + stride, count, IA, rowFlops) : RowMeta{0, 0, 0, 0, 0};
+  RowMeta nxt = NW == 1 ? load_meta_sym(rows, q + stride, count, IA, rowFlops) : RowMeta{0, 0, 0, 0, 0, 0};
   PreA pc = NW == 1 ? load_pre(cur, SBL, nullptr, false) : PreA{0, 0, 0.f, false};
   while (q < count) {
     int qn;
@@ -1155,7 +1176,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ 
     __syncthreads();
     int mine = 0;
     for_each_product<NW, U, false>(st, cur.as, cur.ae, SBL, nullptr, JB, nullptr,
-                                   [&](const auto& act, const auto& col, const auto& val) {
+                                   [&](const auto& act, const auto& col, const auto& val, int) {
       mine += hash_insert_multi(keys, size, shift, act, col, reinterpret_cast<int*>(&st.dummy[lane_id()]), err);
     }, pc, err);
     const int ws = __builtin_amdgcn_readfirstlane(mine);   // hash_insert_multi counts per wave
@@ -1182,7 +1203,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
                                                          const float* __restrict__ VB,
                                                          const int* __restrict__ IC, int* __restrict__ JC,
                                                          float* __restrict__ C, int* __restrict__ err,
-                                                         int* __restrict__ qctr) {
+                                                         int* __restrict__ qctr, const int* __restrict__ rowFlops) {
   __shared__ __attribute__((aligned(16))) slot_t tab[TBL];   // (column, value) pairs
   __shared__ typename WalkSel<NW>::type st;
   __shared__ int qslot;
@@ -1199,8 +1220,9 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
   }
   const int* rows = rowIds + first;
   int q = NW > 1 ? next_row<QB>(qctr, &qslot, -1) : (int)(blockIdx.x >> 3);
-  RowMeta cur = load_meta_num(rows, q, count, IA, IC);
-  RowMeta nxt = NW == 1 ? load_meta_num(rows, q + stride, count, IA, IC) : RowMeta{0, 0, 0, 0, 0};
+  const int* const rf = NW == 1 ? rowFlops : nullptr;    // wave-per-row: the product count decides hash vs expansion
+  RowMeta cur = load_meta_num(rows, q, count, IA, IC, rf);
+  RowMeta nxt = NW == 1 ? load_meta_num(rows, q + stride, count, IA, IC, rf) : RowMeta{0, 0, 0, 0, 0, 0};
   PreA pc = NW == 1 ? load_pre(cur, SBL, VA, true) : PreA{0, 0, 0.f, false};
   while (q < count) {
     int qn;
@@ -1208,7 +1230,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
     RowMeta nn{0, 0, 0, 0, 0};
     if (NW == 1) {
       qn = q + stride;
-      nn = load_meta_num(rows, qn + stride, count, IA, IC);
+      nn = load_meta_num(rows, qn + stride, count, IA, IC, rf);
       pn = load_pre(nxt, SBL, VA, true);
     } else {
       qn = next_row<QB>(qctr, &qslot, q);
@@ -1216,6 +1238,27 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
     }
     const int off = cur.x0;
     const int want = cur.x1 - off;                      // exact distinct count from the symbolic pass
+    if (NW == 1 && want == cur.x2) {
+      // As many distinct columns as products: no two products of this row meet, nothing to accumulate.  The row is
+      // EXPANDED: every product goes straight to the position it has in the row's own numbering -- coalesced stores,
+      // no table, no clear, no compaction sweep (more than half of the products of rows up to 256 products on a
+      // power-law matrix sit in such rows).
+      int* const JCrow = JC + off;
+      float* const Crow = C + off;
+      for_each_product<NW, U, true>(st, cur.as, cur.ae, SBL, VA, JB, VB,
+                                    [&](const auto& act, const auto& col, const auto& val, int p0) {
+        constexpr int R = (int)(sizeof(col) / sizeof(col[0]));
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          const unsigned o = (unsigned)(p0 + u * WAVE + lane_id());
+          if (act[u] && o < (unsigned)want) { JCrow[o] = col[u]; Crow[o] = val[u]; }
+        }
+      }, pc, err);
+      cur = nxt;
+      if (NW == 1) { nxt = nn; pc = pn; }
+      q = qn;
+      continue;
+    }
     const int size = table_size(want, T > 64 ? T : 64, TBL);
     const int shift = 32 - log2_pow2(size);
     clear_slots(tab, size, tid, T);
@@ -1223,7 +1266,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
     __syncthreads();
     if (!ABL(8))
     for_each_product<NW, U, true>(st, cur.as, cur.ae, SBL, VA, JB, VB,
-                                  [&](const auto& act, const auto& col, const auto& val) {
+                                  [&](const auto& act, const auto& col, const auto& val, int) {
       if (ABL(1)) {
 #pragma unroll
         for (int u = 0; u < (int)(sizeof(col) / sizeof(col[0])); ++u) asm volatile("" :: "v"(col[u]), "v"(val[u]));
@@ -1348,7 +1391,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sym_big(const int* __restrict__
       for (int i = tid * 4; i < words4; i += BIG_THREADS * 4) *reinterpret_cast<uint4*>(&sh.bitmap[i]) = make_uint4(0u, 0u, 0u, 0u);
       __syncthreads();
       for_each_product<BIG_NW, BIG_U, false>(sh.st, as, ae, SBL, nullptr, JB, nullptr,
-                                             [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&)[BIG_U]) {
+                                             [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&)[BIG_U], int) {
 #pragma unroll
         for (int u = 0; u < BIG_U; ++u) {            // predicated by value: OR-ing 0 changes nothing
           const int c = col[u] - w0;
@@ -1401,7 +1444,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
       for (int i = tid; i < BIG_WORDS; i += BIG_THREADS) sh.bitmap[i] = 0u;
       __syncthreads();
       for_each_product<BIG_NW, BIG_U, false>(sh.st, as, ae, SBL, nullptr, JB, nullptr,
-                                             [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&)[BIG_U]) {
+                                             [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&)[BIG_U], int) {
 #pragma unroll
         for (int u = 0; u < BIG_U; ++u) {
           const bool ok = act[u] && (unsigned)col[u] < (unsigned)n;
@@ -1462,7 +1505,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
       for (int i = tid; i < span; i += BIG_THREADS) sh.acc[i] = 0.f;
       __syncthreads();
       for_each_product<BIG_NW, BIG_U, true>(sh.st, as, ae, SBL, VA, JB, VB,
-                                            [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&val)[BIG_U]) {
+                                            [&](const bool (&act)[BIG_U], const int (&col)[BIG_U], const float (&val)[BIG_U], int) {
         int rk[BIG_U];
 #pragma unroll
         for (int u = 0; u < BIG_U; ++u) {          // the U rank lookups (two LDS reads each) overlap
@@ -1534,7 +1577,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
       __syncthreads();
       if (pass == 0 || !useSpill) {
         for_each_product<BIG_NW, BH_U, true>(sh.st, as, ae, SBL, VA, JB, VB,
-                                              [&](const bool (&act)[BH_U], const int (&col)[BH_U], const float (&val)[BH_U]) {
+                                              [&](const bool (&act)[BH_U], const int (&col)[BH_U], const float (&val)[BH_U], int) {
           bool mine[BH_U];
           unsigned cls[BH_U];
 #pragma unroll

@@ -376,8 +376,8 @@ static inline int clampi(long long v, int lo, int hi) { return (int)std::max<lon
 static inline int grid8(long long want, int hi) { return (clampi(want, 8, hi) + 7) & ~7; }
 
 static const char* kKernelNames[SPGEMM_NKERNELS] = {
-    "k_row_flops", "k_bin_scan", "k_scatter_rows", "k_sym_small<4,32>", "k_sym_g16", "k_sym_hash<1,1024>",
-    "k_sym_hash<4,4096>", "k_sym_hash<8,8192>", "k_sym_big", "k_scan(3 launches)", "k_num_small<4,32>", "k_num_g16",
+    "k_row_flops", "k_bin_scan", "k_scatter_rows", "k_sym_g16<32,1>", "k_sym_g16", "k_sym_hash<1,1024>",
+    "k_sym_hash<4,4096>", "k_sym_hash<8,8192>", "k_sym_big", "k_scan(3 launches)", "k_num_g16<32,1>", "k_num_g16",
     "k_num_hash<1,1024>", "k_num_hash<4,4096>", "k_num_hash<8,8192>", "k_num_big", "k_num_bighash", "", "", ""};
 extern "C" const char* spgemm_hip_kernel_name(int id) { return (id >= 0 && id < SPGEMM_NKERNELS) ? kKernelNames[id] : ""; }
 
@@ -476,10 +476,10 @@ static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJB,
     LAUNCH_U(k_sym_hash, 1, 1024, dim3(grid8(m, cu * h->h1sym)), dim3(64), st, sb, SLOT_H1B, rowIds, dIA,
              sbl, dJB, h->rowFlops, dIC, err, qc + 3); }
   { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_SYM_G16, st);
-    hipLaunchKernelGGL((k_sym_g16<128, 4>), dim3(grid8(cdiv(m, 16), cu * 16)), dim3(256), 0, st, bp, 4,
+    hipLaunchKernelGGL((k_sym_g16<128, 4>), dim3(grid8(cdiv(m, 16), cu * 16)), dim3(256), 0, st, bp, 4, 5,
                        rowIds, dIA, sbl, dJB, h->rowFlops, dIC, err); }
-  { KTimer t(h, SPGEMM_K_SYM_SMALL4);
-    hipLaunchKernelGGL((k_sym_small<4, 32>), dim3(grid8(cdiv(m, 64), cu * 8)), dim3(256), 0, h->stream, bp, 2, 4,
+  { KTimer t(h, SPGEMM_K_SYM_SMALL4);           // 2..16 products: the same 16-lane flattened kernel, one round per row
+    hipLaunchKernelGGL((k_sym_g16<32, 1>), dim3(grid8(cdiv(m, 16), cu * 16)), dim3(256), 0, h->stream, bp, 2, 4,
                        rowIds, dIA, sbl, dJB, h->rowFlops, dIC, err); }
   join_streams(h);
   HIPCHK(hipGetLastError());
@@ -528,24 +528,24 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
   }
   if (rows(7, 8) > 0) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_NUM_HASH8, st);
     LAUNCH_U(k_num_hash, 8, 8192, dim3(clampi(rows(7, 8), 1, cu * 2)), dim3(512), st, bp, 7,
-             rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 5); }
+             rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 5, h->rowFlops); }
   if (rows(6, 7) > 0) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_NUM_HASH4, st);
     LAUNCH_U(k_num_hash, 4, 4096, dim3(clampi(rows(6, 7), 1, cu * 4)), dim3(256), st, bp, 6,
-             rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 6); }
+             rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 6, h->rowFlops); }
   if (rows(5, 6) > 0) { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_NUM_HASH1, st);
     const int* sb = h->dsmall->slotBase;
     const int* hs_ = h->mirror.slotBase;
     const int na = hs_[SLOT_H1A + 1] - hs_[SLOT_H1A], nb = hs_[SLOT_H1B + 1] - hs_[SLOT_H1B];
     if (na > 0) LAUNCH_U(k_num_hash, 1, 512, dim3(grid8(na, cu * 24)), dim3(64), st, sb, SLOT_H1A,
-                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7);
+                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7, h->rowFlops);
     if (nb > 0) LAUNCH_U(k_num_hash, 1, 1024, dim3(grid8(nb, cu * 16)), dim3(64), st, sb, SLOT_H1B,
-                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7); }
+                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7, h->rowFlops); }
   if (rows(4, 5) > 0) { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_NUM_G16, st);
     hipLaunchKernelGGL((k_num_g16<128, 4>), dim3(grid8(cdiv(rows(4, 5), 16), cu * 16)), dim3(256), 0, st,
-                       bp, 4, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err); }
-  if (rows(1, 4) > 0) { KTimer t(h, SPGEMM_K_NUM_SMALL4);
-    hipLaunchKernelGGL((k_num_small<4, 32>), dim3(grid8(cdiv(rows(1, 4), 64), cu * 8)), dim3(256), 0, h->stream, bp,
-                       1, 4, rowIds, dIA, sbl, dA, dJB, dB, h->rowFlops, dIC, dJC, dC, err); }
+                       bp, 4, 5, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, h->rowFlops); }
+  if (rows(1, 4) > 0) { KTimer t(h, SPGEMM_K_NUM_SMALL4);   // 1..16 products: 16-lane flattened kernel, one round per row
+    hipLaunchKernelGGL((k_num_g16<32, 1>), dim3(grid8(cdiv(rows(1, 4), 16), cu * 16)), dim3(256), 0, h->stream,
+                       bp, 1, 4, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, h->rowFlops); }
   join_streams(h);
   HIPCHK(hipGetLastError());
   return SPGEMM_OK;
