@@ -58,26 +58,29 @@ __host__ __device__ __forceinline__ int bin_of(unsigned long long f) {
 //   slots 5, 6  = bin 5 split at 256 products: rows up to 256 products need a 512-slot table, so their wave-per-row
 //                 kernel fits 24 blocks per CU instead of 16 (measured on the symbolic kernel: 16 -> 24 waves/CU is
 //                 17 % faster, 32 is slower again)
-//   slots 7, 8  = bins 6, 7
-//   slots 9..15 = the last bin split into NSUB size classes (4097-8191, 8192-16383, ... by powers of two) laid out
+//   slots 7, 8  = bin 6 split at 1024 products: a 2048-slot table lets 7 four-wave blocks share a CU instead of 4 (these
+//                 kernels are bound by the serial chain of a row times the rows in flight, not by any unit's throughput)
+//   slot  9     = bin 7
+//   slots 10..15 = the last bin split into NSUB size classes (4097-8191, 8192-16383, ... by powers of two) laid out
 //                 LARGEST FIRST, so that the work queue of the block-per-row kernels hands out the heavy rows first
 //                 and the kernel does not end on one of them (measured: k_num_bighash 1.58 -> 1.48 ms at 1 M rows)
-constexpr int NSUB = 7;
-constexpr int SLOT_H1A = 5, SLOT_H1B = 6, SLOT_H4 = 7, SLOT_H8 = 8, SLOT_BIG0 = 9;
+constexpr int NSUB = 6;
+constexpr int SLOT_H1A = 5, SLOT_H1B = 6, SLOT_H4A = 7, SLOT_H4B = 8, SLOT_H8 = 9, SLOT_BIG0 = 10;
 constexpr int NSLOTS = SLOT_BIG0 + NSUB;
-constexpr int H1A_MAX = 256;
+constexpr int H1A_MAX = 256, H4A_MAX = 1024;
 __host__ __device__ __forceinline__ int slot_of(unsigned long long f) {
   const int b = bin_of(f);
   if (b < 5) return b;
   if (b == 5) return f <= (unsigned)H1A_MAX ? SLOT_H1A : SLOT_H1B;
-  if (b < NBINS - 1) return b + 1;
+  if (b == 6) return f <= (unsigned)H4A_MAX ? SLOT_H4A : SLOT_H4B;
+  if (b == 7) return SLOT_H8;
   int lg = 12;                                        // f >= 4097
   while (lg < 12 + NSUB - 1 && (f >> (lg + 1)) != 0) ++lg;
   return SLOT_BIG0 + (NSUB - 1 - (lg - 12));
 }
 // last slot of a bin
 __host__ __device__ __forceinline__ int last_slot_of_bin(int b) {
-  return b < 5 ? b : b == 5 ? SLOT_H1B : b < NBINS - 1 ? b + 1 : NSLOTS - 1;
+  return b < 5 ? b : b == 5 ? SLOT_H1B : b == 6 ? SLOT_H4B : b == 7 ? SLOT_H8 : NSLOTS - 1;
 }
 
 // error flag bits written by kernels into Workspace::d_err

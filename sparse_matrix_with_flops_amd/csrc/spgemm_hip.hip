@@ -141,7 +141,7 @@ DevPool& pool() { static DevPool* p = new DevPool(); return *p; }
 struct HostMirror {                 // one small device block + its pinned host twin, copied once per phase
   int binPtr[NBINS + 1];
   int err;
-  int scratch2[3];                  // counts of the 513-2048 / 2049-4096 / 65-256 rows when a classification is unpacked
+  int scratch2[4];                  // counts of the 513-2048 / 2049-4096 / 65-256 / 513-1024 rows when a classification is unpacked
   int qctr[8];                      // work-queue heads of the block-per-row kernels (zeroed with the rest per call)
   int slotBase[NSLOTS + 1];         // first position of every layout slot in rowIds, [NSLOTS] = m (k_bin_scan)
   unsigned long long totalP;
@@ -467,6 +467,7 @@ static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJB,
     LAUNCH_U(k_sym_hash, 8, 8192, dim3(clampi(m, 1, cu * 3)), dim3(512), st, bp, 7, rowIds, dIA,
              sbl, dJB, h->rowFlops, dIC, err, qc + 1); }
   { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_SYM_HASH4, st);
+    // (one launch for both layout slots of bin 6: split like the numeric side it measured 15 % slower)
     LAUNCH_U(k_sym_hash, 4, 4096, dim3(clampi(m, 1, cu * 8)), dim3(256), st, bp, 6, rowIds, dIA,
              sbl, dJB, h->rowFlops, dIC, err, qc + 2); }
   { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_SYM_HASH1, st);
@@ -530,8 +531,13 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
     LAUNCH_U(k_num_hash, 8, 8192, dim3(clampi(rows(7, 8), 1, cu * 2)), dim3(512), st, bp, 7,
              rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 5, h->rowFlops); }
   if (rows(6, 7) > 0) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_NUM_HASH4, st);
-    LAUNCH_U(k_num_hash, 4, 4096, dim3(clampi(rows(6, 7), 1, cu * 4)), dim3(256), st, bp, 6,
-             rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 6, h->rowFlops); }
+    const int* sb = h->dsmall->slotBase;
+    const int* hs_ = h->mirror.slotBase;
+    const int na = hs_[SLOT_H4A + 1] - hs_[SLOT_H4A], nb = hs_[SLOT_H4B + 1] - hs_[SLOT_H4B];
+    if (na > 0) LAUNCH_U(k_num_hash, 4, 2048, dim3(clampi(na, 1, cu * 7)), dim3(256), st, sb, SLOT_H4A,
+                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 6, h->rowFlops);
+    if (nb > 0) LAUNCH_U(k_num_hash, 4, 4096, dim3(clampi(nb, 1, cu * 4)), dim3(256), st, sb, SLOT_H4B,
+                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7, h->rowFlops); }
   if (rows(5, 6) > 0) { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_NUM_HASH1, st);
     const int* sb = h->dsmall->slotBase;
     const int* hs_ = h->mirror.slotBase;
@@ -870,7 +876,7 @@ extern "C" int hip_gpuFlopsClassify(spgemm_handle* h, const int* dIA, const int*
 __global__ void k_unpack_classify(int m, const int* __restrict__ rowIds, const int* __restrict__ dflops,
                                   int* __restrict__ rowFlops, int* __restrict__ IC, int lo6, int* __restrict__ n67) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  int is6 = 0, is7 = 0, is5a = 0;
+  int is6 = 0, is7 = 0, is5a = 0, is6a = 0;
   if (q < m) {
     const int r = rowIds[q];
     // dflops is an int scan (like the reference's): differences stay exact modulo 2^32
@@ -880,9 +886,11 @@ __global__ void k_unpack_classify(int m, const int* __restrict__ rowIds, const i
     is6 = (q >= lo6 && f <= 2048u) ? 1 : 0;
     is7 = (q >= lo6 && f > 2048u && f <= 4096u) ? 1 : 0;
     is5a = (f > 64u && f <= (unsigned)smf::H1A_MAX) ? 1 : 0;
+    is6a = (q >= lo6 && f <= (unsigned)smf::H4A_MAX) ? 1 : 0;
   }
-  const unsigned long long m6 = __ballot(is6), m7 = __ballot(is7), m5 = __ballot(is5a);
+  const unsigned long long m6 = __ballot(is6), m7 = __ballot(is7), m5 = __ballot(is5a), m6a = __ballot(is6a);
   if (smf::lane_id() == 0) {
+    if (m6a) atomicAdd(&n67[3], __popcll(m6a));
     if (m6) atomicAdd(&n67[0], __popcll(m6));
     if (m7) atomicAdd(&n67[1], __popcll(m7));
     if (m5) atomicAdd(&n67[2], __popcll(m5));
@@ -895,7 +903,8 @@ __global__ void k_binptr_from_hv(int* binPtr, int* slotBase, int h2, int h3, int
     binPtr[0] = 0; binPtr[1] = h2 - 1; binPtr[2] = h3 - 1; binPtr[3] = h4 - 1; binPtr[4] = h5 - 1;
     binPtr[5] = h6 - 1; binPtr[6] = h7 - 1; binPtr[7] = h7 - 1 + n67[0]; binPtr[8] = binPtr[7] + n67[1]; binPtr[9] = m;
     // the two layout slots of bin 5 (the classification came from hip_gpuFlopsClassify: <=256 products first)
-    slotBase[smf::SLOT_H1A] = binPtr[5]; slotBase[smf::SLOT_H1B] = binPtr[5] + n67[2]; slotBase[smf::SLOT_H4] = binPtr[6];
+    slotBase[smf::SLOT_H1A] = binPtr[5]; slotBase[smf::SLOT_H1B] = binPtr[5] + n67[2]; slotBase[smf::SLOT_H4A] = binPtr[6];
+    slotBase[smf::SLOT_H4B] = binPtr[6] + n67[3]; slotBase[smf::SLOT_H8] = binPtr[7];
   }
 }
 
