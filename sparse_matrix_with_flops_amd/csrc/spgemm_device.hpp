@@ -38,6 +38,16 @@ __device__ int g_ablate = 0;
 #endif
 
 constexpr int WAVE = 64;
+
+// C is written once and not read again by this call: its stores carry the non-temporal hint so that the output stream
+// does not push B out of the caches the gathers live on
+template <class T> __device__ __forceinline__ void st_out(T* p, T v) {
+#ifdef SMF_PLAIN_STORES
+  *p = v;
+#else
+  __builtin_nontemporal_store(v, p);
+#endif
+}
 constexpr int NBINS = 9;  // {0 | 1 | 2-4 | 5-16 | 17-64 | 65-512 | 513-2048 | 2049-4096 | >4096}
 constexpr int EMPTY_KEY = -1;
 
@@ -371,7 +381,7 @@ __device__ __forceinline__ void emit_claimed(const slot_t* tab, int base, int pe
     const bool occ = slot_key(sl[sidx]) != EMPTY_KEY;
     const unsigned long long mk = ballot64(occ);
     const unsigned o = (unsigned)(pos + mask_rank(mk));
-    if (occ && o < lim) { JCrow[o] = slot_key(sl[sidx]); Crow[o] = slot_val(sl[sidx]); }
+    if (occ && o < lim) { st_out(JCrow + o, slot_key(sl[sidx])); st_out(Crow + o, slot_val(sl[sidx])); }
     pos += __popcll(mk);
   }
 }
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(256) void k_num_small(const int* __restrict__ binPt
       const int shiftg = lane_id() - gl;
       const unsigned long long gm = (G == 64) ? mk : ((mk >> shiftg) & ((1ull << G) - 1ull));
       const int rank = __popcll(gm & ((1ull << gl) - 1ull));
-      if (occ) { JC[off + written + rank] = slot_key(sv); C[off + written + rank] = slot_val(sv); }
+      if (occ) { st_out(JC + off + written + rank, slot_key(sv)); st_out(C + off + written + rank, slot_val(sv)); }
       written += __popcll(gm);
     }
     if (live && gl == 0 && written != want) atomicOr(err, ERRF_COUNT_MISMATCH);
@@ -797,7 +807,7 @@ __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr,
     if (ballot64(hashRow) == 0ull) {
       if (live) {
         g16_walk<U, true>(st[g], gl, IA[row], IA[row + 1], SBL, VA, JB, VB, [&](bool active, int col, float v, int pos) {
-          if (active && (unsigned)pos < (unsigned)want) { JC[off + pos] = col; C[off + pos] = v; }
+          if (active && (unsigned)pos < (unsigned)want) { st_out(JC + off + pos, col); st_out(C + off + pos, v); }
         });
       }
       continue;
@@ -819,7 +829,7 @@ __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr,
       const unsigned long long mk = ballot64(occ);
       const unsigned gm = (unsigned)(mk >> (lane_id() - gl)) & 0xffffu;
       const int rank = __popc(gm & ((1u << gl) - 1u));
-      if (occ) { JC[off + written + rank] = slot_key(sv); C[off + written + rank] = slot_val(sv); }
+      if (occ) { st_out(JC + off + written + rank, slot_key(sv)); st_out(C + off + written + rank, slot_val(sv)); }
       written += __popc(gm);
     }
     if (live && gl == 0 && written != want) atomicOr(err, ERRF_COUNT_MISMATCH);
@@ -1254,7 +1264,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
 #pragma unroll
         for (int u = 0; u < R; ++u) {
           const unsigned o = (unsigned)(p0 + u * WAVE + lane_id());
-          if (act[u] && o < (unsigned)want) { JCrow[o] = col[u]; Crow[o] = val[u]; }
+          if (act[u] && o < (unsigned)want) { st_out(JCrow + o, col[u]); st_out(Crow + o, val[u]); }
         }
       }, pc, err);
       cur = nxt;
@@ -1292,7 +1302,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
         const bool occ = slot_key(sv) != EMPTY_KEY;
         const unsigned long long mk = ballot64(occ);
         const unsigned o = (unsigned)(pos + mask_rank(mk));
-        if (occ && o < (unsigned)want) { JCrow[o] = slot_key(sv); Crow[o] = slot_val(sv); }
+        if (occ && o < (unsigned)want) { st_out(JCrow + o, slot_key(sv)); st_out(Crow + o, slot_val(sv)); }
         pos += __popcll(mk);
       }
       if (tid == 0 && pos != want) atomicOr(err, ERRF_COUNT_MISMATCH);
@@ -1503,7 +1513,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
         }
       }
       __syncthreads();
-      for (int i = tid; i < span; i += BIG_THREADS) JC[outBase + lo + i] = accI[i];
+      for (int i = tid; i < span; i += BIG_THREADS) st_out(JC + outBase + lo + i, accI[i]);
       __syncthreads();
       for (int i = tid; i < span; i += BIG_THREADS) sh.acc[i] = 0.f;
       __syncthreads();
@@ -1522,7 +1532,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_big(const int* __restrict__
           ok[u] = act[u] && (unsigned)col[u] < (unsigned)n && (unsigned)rk[u] < (unsigned)span;
         lds_fadd_multi(sh.acc, rk, ok, val, reinterpret_cast<int*>(&sh.st.dummy[lane_id()]));
       });
-      for (int i = tid; i < span; i += BIG_THREADS) C[outBase + lo + i] = sh.acc[i];
+      for (int i = tid; i < span; i += BIG_THREADS) st_out(C + outBase + lo + i, sh.acc[i]);
       __syncthreads();
     }
     __syncthreads();

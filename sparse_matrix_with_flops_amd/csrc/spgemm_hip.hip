@@ -534,6 +534,9 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
     const int* sb = h->dsmall->slotBase;
     const int* hs_ = h->mirror.slotBase;
     const int na = hs_[SLOT_H4A + 1] - hs_[SLOT_H4A], nb = hs_[SLOT_H4B + 1] - hs_[SLOT_H4B];
+    if (na > 0 && getenv("SPGEMM_H4A_WAVE")) LAUNCH_U(k_num_hash, 1, 2048, dim3(grid8(na, cu * 9)), dim3(64), st, sb, SLOT_H4A,
+                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 6, h->rowFlops);
+    else
     if (na > 0) LAUNCH_U(k_num_hash, 4, 2048, dim3(clampi(na, 1, cu * 7)), dim3(256), st, sb, SLOT_H4A,
                          rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 6, h->rowFlops);
     if (nb > 0) LAUNCH_U(k_num_hash, 4, 4096, dim3(clampi(nb, 1, cu * 4)), dim3(256), st, sb, SLOT_H4B,
