@@ -176,6 +176,17 @@ int hip_rmcl_prune(spgemm_handle* h, int m, const int* dIC, const int* dJC, floa
 /* the same with nnz(C) supplied by the caller (known on the host after every SpGEMM): saves one device read */
 int hip_rmcl_prune_n(spgemm_handle* h, int m, int nnz, const int* dIC, const int* dJC, const float* dC,
                      int** dIN, int** dJN, float** dCN, int* nnzN);
+/* hip_rmcl_expand_prune: one R-MCL iteration on device arrays as ONE operator, Mt' = prune(A * B) (A = Mgt, B = Mt):
+ * what the reference's loop body does with gpuSpMMWrapper + inflate/threshold kernels + thrust::remove
+ * (nlibs/gpus/gpu_csr_kernel.cu:281-311 with :218-270).  The product is never materialised: the numeric kernels apply
+ * the row rule to each finished row in LDS and write only the kept entries.  Same results as hip_gpuSpMM followed by
+ * hip_rmcl_prune up to the summation order of the row sums (entries within float rounding of the threshold).
+ * Outputs allocated here (release with spgemm_hip_free); rows keep the order the product kernels emit (unsorted). */
+int hip_rmcl_expand_prune(spgemm_handle* h,
+                          const int* dIA, const int* dJA, const float* dA, int nnzA,
+                          const int* dIB, const int* dJB, const float* dB, int nnzB,
+                          int m, int k, int n,
+                          int** dIN, int** dJN, float** dCN, int* nnzN);
 int hip_gpuRmclIter(int maxIter, int rows, int cols,
                     const int* gIA, const int* gJA, const float* gA, int gnnz,
                     const int* tIA, const int* tJA, const float* tA, int tnnz,

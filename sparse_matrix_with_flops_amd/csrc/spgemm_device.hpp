@@ -9,7 +9,7 @@
 //                          group_CSR_flops counting sort     nlibs/group_csr_kernel.cc:24-51
 //   k_sym_*                sgpu_CSR_IC_nnzC_mid*             mindex2-cuda/tryOutBins.cuh:5-131
 //                          gpu_CSR_IC_nnzC                   nlibs/gpus/gpu_csr_kernel.cu:44-82
-//   k_num_small/k_num_hash sgpu_SpGEMM_mid / fp1 / fp2 / fpl4 mindex2-cuda/gspgemm.cuh:2-293
+//   k_num_g16/k_num_hash   sgpu_SpGEMM_mid / fp1 / fp2 / fpl4 mindex2-cuda/gspgemm.cuh:2-293
 //                          hashCASAdd2                       mindex2-cuda/casHash.cuh:34-43
 //   k_num_big*             sgpu_SpGEMM_olarge (dense map)    "mindex2-cuda/\":143-213
 //
@@ -387,6 +387,162 @@ __device__ __forceinline__ void emit_claimed(const slot_t* tab, int base, int pe
 }
 
 // ------------------------------------------------------------------------------------------------
+// R-MCL row rule (CPU: nlibs/tools/util.cc:4-69; reference GPU: nlibs/gpus/dutil.cuh:8-80): inflate (square), max,
+// sum, thresh = clamp(0.9*avg*(1-2(max-avg)), 1e-7, max), keep v >= thresh, divide the kept values by their sum.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rmcl_threshold(float avg, float mx) {
+  float ret = (float)(0.90 * avg * (1 - 2 * (mx - avg)));       // same promotions as computeThreshold (util.cc:4-9)
+  ret = (float)((ret > 1.0e-7) ? ret : 1.0e-7);
+  ret = (ret > mx) ? mx : ret;
+  return ret;
+}
+
+// all-reduce inside the L lanes that share a row (L = 16: one DPP row; L = 64: the wave).  DPP butterflies (xor 1, xor 2,
+// half-row mirror, row mirror): four VALU ops for 16 lanes and no LDS round trip -- a ds_bpermute chain here costs more
+// than the whole product walk of a 100-product row.  64 lanes: the four row results are combined in a fixed order.
+template <class Op>
+__device__ __forceinline__ float row16_allreduce(float v, Op op) {
+  v = op(v, __int_as_float(SMF_DPP(__float_as_int(v), 0xB1, 0xf, 0)));    // quad_perm [1,0,3,2]
+  v = op(v, __int_as_float(SMF_DPP(__float_as_int(v), 0x4E, 0xf, 0)));    // quad_perm [2,3,0,1]
+  v = op(v, __int_as_float(SMF_DPP(__float_as_int(v), 0x141, 0xf, 0)));   // row_half_mirror
+  v = op(v, __int_as_float(SMF_DPP(__float_as_int(v), 0x140, 0xf, 0)));   // row_mirror
+  return v;
+}
+template <int L, class Op>
+__device__ __forceinline__ float rowL_allreduce(float v, Op op) {
+  static_assert(L == 16 || L == 64, "16-lane groups or whole waves");
+  v = row16_allreduce(v, op);
+  if (L == 64) {
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    v = op(op(r0, r1), op(r2, r3));
+  }
+  return v;
+}
+template <int L> __device__ __forceinline__ float rowL_sum(float v) { return rowL_allreduce<L>(v, [](float a, float b) { return a + b; }); }
+template <int L> __device__ __forceinline__ float rowL_max(float v) { return rowL_allreduce<L>(v, [](float a, float b) { return fmaxf(a, b); }); }
+// this group's 16 (or all 64) bits of a wave-wide lane mask
+template <int L>
+__device__ __forceinline__ unsigned long long group_mask(unsigned long long mk, int gl) {
+  return L == 64 ? mk : ((mk >> (lane_id() - gl)) & 0xffffull);
+}
+
+// Fused expansion + prune (hip_rmcl_expand_prune): the row rule applied to a finished row that still sits in LDS, so
+// that only the KEPT entries (about a quarter of an R-MCL product) ever reach HBM.  They are written, normalised, to
+// the FRONT of the row's range of the scratch arrays, their count to cnt[row]; k_rmcl_move then packs the rows.
+// The slots hold either a hash table (occupied = key set) or the plain list of the row's `want` products (expanded rows).
+// L lanes share the row (a 16-lane group or a whole wave) and sweep slots [0, per), per a multiple of L.
+// want < 0: the number of distinct columns is not known beforehand (no symbolic pass ran), the occupied slots are counted.
+template <int L>
+__device__ __forceinline__ int prune_emit_group(const slot_t* tab, int per, int want, bool byKey, bool live, int gl,
+                                                int* __restrict__ JCrow, float* __restrict__ Crow, int* nocc) {
+  float mx = 0.f, sum = 0.f;
+  int n = 0;
+  for (int i0 = 0; i0 < per; i0 += L) {
+    const slot_t sv = tab[i0 + gl];
+    const bool occ = live && (byKey ? slot_key(sv) != EMPTY_KEY : i0 + gl < want);
+    const float c = slot_val(sv), v = occ ? c * c : 0.f;
+    mx = fmaxf(mx, v);
+    sum += v;
+    n += __popcll(group_mask<L>(ballot64(occ), gl));
+  }
+  mx = rowL_max<L>(mx);
+  sum = rowL_sum<L>(sum);
+  *nocc = n;
+  const float th = rmcl_threshold(sum / (float)(want >= 0 ? want : n), mx);
+  float ks = 0.f;
+  for (int i0 = 0; i0 < per; i0 += L) {
+    const slot_t sv = tab[i0 + gl];
+    const bool occ = live && (byKey ? slot_key(sv) != EMPTY_KEY : i0 + gl < want);
+    const float c = slot_val(sv), v = c * c;
+    ks += (occ && v >= th) ? v : 0.f;
+  }
+  ks = rowL_sum<L>(ks);
+  const float inv = 1.0f / ks;                        // one division per row; v*inv is within an ulp of v/ks
+  int pos = 0;
+  for (int i0 = 0; i0 < per; i0 += L) {
+    const slot_t sv = tab[i0 + gl];
+    const bool occ = live && (byKey ? slot_key(sv) != EMPTY_KEY : i0 + gl < want);
+    const float c = slot_val(sv), v = c * c;
+    const bool keep = occ && v >= th;
+    const unsigned long long gm = group_mask<L>(ballot64(keep), gl);
+    if (keep) {
+      const int o = pos + __popcll(gm & ((1ull << gl) - 1ull));
+      st_out(JCrow + o, slot_key(sv));
+      st_out(Crow + o, v * inv);
+    }
+    pos += __popcll(gm);
+  }
+  return pos;
+}
+
+// the same for a block of NW waves whose wave w owns slots [w*per, w*per+per) of a hash table: slots into registers,
+// two block reductions (partials summed in wave order by every thread: the result does not depend on timing)
+template <int NW> struct PruneShared { float mx[NW], sum[NW], ks[NW]; int occ[NW], kc[NW]; };
+
+template <int NW, int MAXSTEPS>
+__device__ __forceinline__ void prune_emit_block(const slot_t* tab, int per, int want, PruneShared<NW>& ps,
+                                                 int* __restrict__ JCrow, float* __restrict__ Crow,
+                                                 int* __restrict__ cntRow, int* __restrict__ err) {
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  slot_t sl[MAXSTEPS];
+  float v[MAXSTEPS];                                  // squared value; -1 marks an empty slot (never >= a threshold)
+  float mx = 0.f, sum = 0.f;
+  int n = 0;
+#pragma unroll
+  for (int sidx = 0; sidx < MAXSTEPS; ++sidx) {
+    sl[sidx] = sidx * WAVE < per ? tab[w * per + sidx * WAVE + lane] : EMPTY_SLOT;
+    const bool occ = slot_key(sl[sidx]) != EMPTY_KEY;
+    const float c = slot_val(sl[sidx]);
+    v[sidx] = occ ? c * c : -1.f;
+    mx = fmaxf(mx, v[sidx]);
+    sum += occ ? v[sidx] : 0.f;
+    n += __popcll(ballot64(occ));
+  }
+  mx = rowL_max<64>(mx);
+  sum = rowL_sum<64>(sum);
+  if (lane == 0) { ps.mx[w] = mx; ps.sum[w] = sum; ps.occ[w] = n; }
+  __syncthreads();
+  mx = 0.f; sum = 0.f; n = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) { mx = fmaxf(mx, ps.mx[i]); sum += ps.sum[i]; n += ps.occ[i]; }
+  const float th = rmcl_threshold(sum / (float)(want >= 0 ? want : n), mx);
+  float ks = 0.f;
+  int kc = 0;
+#pragma unroll
+  for (int sidx = 0; sidx < MAXSTEPS; ++sidx) {
+    const bool keep = v[sidx] >= th;
+    ks += keep ? v[sidx] : 0.f;
+    kc += __popcll(ballot64(keep));
+  }
+  ks = rowL_sum<64>(ks);
+  if (lane == 0) { ps.ks[w] = ks; ps.kc[w] = kc; }
+  __syncthreads();
+  ks = 0.f;
+  int pos = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) { ks += ps.ks[i]; pos += i < w ? ps.kc[i] : 0; total += ps.kc[i]; }
+  const float inv = 1.0f / ks;
+#pragma unroll
+  for (int sidx = 0; sidx < MAXSTEPS; ++sidx) {
+    const bool keep = v[sidx] >= th;
+    const unsigned long long mk = ballot64(keep);
+    if (keep) {
+      const int o = pos + mask_rank(mk);
+      st_out(JCrow + o, slot_key(sl[sidx]));
+      st_out(Crow + o, v[sidx] * inv);
+    }
+    pos += __popcll(mk);
+  }
+  if (threadIdx.x == 0) {
+    *cntRow = total;
+    if (want >= 0 && n != want) atomicOr(err, ERRF_COUNT_MISMATCH);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1  per-row product count + bin id + per-block bin histogram            (mindex2: gcomputeFlops)
 // One wave owns 64 consecutive rows.  Phase 1: every lane walks the first FL_SHORT entries of its own
 // row (87% of the rows of a power-law matrix end there).  Phase 2: rows that are longer are finished by
@@ -560,113 +716,7 @@ __device__ __forceinline__ XcdRange xcd_range(int count) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Small rows (<= 64 products): a group of G lanes per row, A entries one after the other, the G
-// lanes stride the (short, bounded by the bin) B row.  Tables live in LDS, one per group, sized per
-// row to the next power of two >= 2*flops.
-// ------------------------------------------------------------------------------------------------
-template <int G, int TBL>
-__global__ __launch_bounds__(256) void k_sym_small(const int* __restrict__ binPtr, int binLo, int binHi,
-                                                    const int* __restrict__ rowIds,
-                                                    const int* __restrict__ IA, const int2* __restrict__ SBL,
-                                                    const int* __restrict__ JB,
-                                                    const int* __restrict__ rowFlops, int* __restrict__ IC,
-                                                    int* __restrict__ err) {
-  constexpr int GROUPS = 256 / G;
-  __shared__ int keys[GROUPS][TBL];
-  const int tid = threadIdx.x, g = tid / G, gl = tid % G;
-  const int first = binPtr[binLo], count = binPtr[binHi] - first;
-  const int iters = (count + GROUPS - 1) / GROUPS;   // uniform trip count per block
-  // XCD-contiguous schedule: the blocks that share an XCD (blockIdx % 8, guide "Workgroup dispatch") walk ONE contiguous
-  // eighth of the bin, so that the B rows its A rows have in common are fetched into that XCD's L2 once, not into all eight
-  const XcdRange xr = xcd_range(iters);
-  for (int it = xr.lo + xr.bi; it < xr.hi; it += xr.nb) {
-    const int q = it * GROUPS + g;
-    const bool live = q < count;
-    const int row = live ? rowIds[first + q] : 0;
-    const int F = live ? rowFlops[row] : 1;
-    const int size = table_size(F, 8, TBL);
-    const int shift = 32 - log2_pow2(size);
-    for (int i = gl; i < size; i += G) keys[g][i] = EMPTY_KEY;
-    wave_lds_sync();
-    int mine = 0;
-    if (live) {
-      const int as = IA[row], ae = IA[row + 1];
-      for (int ap = as; ap < ae; ++ap) {
-        const int2 sbl = SBL[ap];
-        const int bs = sbl.x, be = sbl.x + sbl.y;
-        for (int bp = bs + gl; bp < be; bp += G) {
-          bool isnew;
-          hash_insert(keys[g], size, shift, JB[bp], &isnew, err);
-          mine += isnew ? 1 : 0;
-        }
-      }
-    }
-    // group sum (all lanes are back in lock step here)
-#pragma unroll
-    for (int d = G / 2; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
-    if (live && gl == 0) IC[row] = mine;
-    wave_lds_sync();
-  }
-}
-
-template <int G, int TBL>
-__global__ __launch_bounds__(256) void k_num_small(const int* __restrict__ binPtr, int binLo, int binHi,
-                                                    const int* __restrict__ rowIds,
-                                                    const int* __restrict__ IA, const int2* __restrict__ SBL,
-                                                    const float* __restrict__ VA,
-                                                    const int* __restrict__ JB,
-                                                    const float* __restrict__ VB,
-                                                    const int* __restrict__ rowFlops,
-                                                    const int* __restrict__ IC, int* __restrict__ JC,
-                                                    float* __restrict__ C, int* __restrict__ err) {
-  constexpr int GROUPS = 256 / G;
-  __shared__ slot_t tab[GROUPS][TBL];          // (column, value) pairs
-  const int tid = threadIdx.x, g = tid / G, gl = tid % G;
-  const int first = binPtr[binLo], count = binPtr[binHi] - first;
-  const int iters = (count + GROUPS - 1) / GROUPS;
-  // XCD-contiguous schedule: the blocks that share an XCD (blockIdx % 8, guide "Workgroup dispatch") walk ONE contiguous
-  // eighth of the bin, so that the B rows its A rows have in common are fetched into that XCD's L2 once, not into all eight
-  const XcdRange xr = xcd_range(iters);
-  for (int it = xr.lo + xr.bi; it < xr.hi; it += xr.nb) {
-    const int q = it * GROUPS + g;
-    const bool live = q < count;
-    const int row = live ? rowIds[first + q] : 0;
-    const int F = live ? rowFlops[row] : 1;
-    const int size = table_size(F, 8, TBL);
-    const int shift = 32 - log2_pow2(size);
-    for (int i = gl; i < size; i += G) tab[g][i] = EMPTY_SLOT;
-    wave_lds_sync();
-    if (live) {
-      const int as = IA[row], ae = IA[row + 1];
-      for (int ap = as; ap < ae; ++ap) {
-        const int2 sbl = SBL[ap];
-        const float a = VA[ap];
-        const int bs = sbl.x, be = sbl.x + sbl.y;
-        for (int bp = bs + gl; bp < be; bp += G) hash_accum(tab[g], size, shift, JB[bp], a * VB[bp], err);
-      }
-    }
-    wave_lds_sync();
-    // compaction: the G lanes sweep the table; occupied slots are packed in slot order
-    const int off = live ? IC[row] : 0;
-    const int want = live ? IC[row + 1] - off : 0;
-    int written = 0;
-    for (int i0 = 0; i0 < size; i0 += G) {
-      const slot_t sv = tab[g][i0 + gl];
-      const bool occ = live && slot_key(sv) != EMPTY_KEY;
-      const unsigned long long mk = ballot64(occ);
-      const int shiftg = lane_id() - gl;
-      const unsigned long long gm = (G == 64) ? mk : ((mk >> shiftg) & ((1ull << G) - 1ull));
-      const int rank = __popcll(gm & ((1ull << gl) - 1ull));
-      if (occ) { st_out(JC + off + written + rank, slot_key(sv)); st_out(C + off + written + rank, slot_val(sv)); }
-      written += __popcll(gm);
-    }
-    if (live && gl == 0 && written != want) atomicOr(err, ERRF_COUNT_MISMATCH);
-    wave_lds_sync();
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Rows with 17..64 products: 16 lanes per row (4 rows per wave), products flattened over the 16 lanes.
+// Rows with 1..64 products: 16 lanes per row (4 rows per wave), products flattened over the 16 lanes.
 // The old "A entries one after the other" walk costs three dependent memory round trips per A entry;
 // here a row costs three in total (JA -> IB -> JB/VB): the row's A entries are staged 16 at a time with a
 // 16-lane DPP scan of their B-row lengths, then 16-product rounds find their entry by a 4-step search.
@@ -776,7 +826,10 @@ __global__ __launch_bounds__(256) void k_sym_g16(const int* __restrict__ binPtr,
   }
 }
 
-template <int TBL, int U>
+// PRUNE: 0 plain product; 1 fused R-MCL prune, IC = exact row pointers of the product (symbolic pass ran); 2 fused prune
+// WITHOUT a symbolic pass: IC = prefix sums of the rows' product counts (an upper bound of every row), every row is hashed
+// in a table sized by its products and the distinct columns are counted by the epilogue itself.
+template <int TBL, int U, int PRUNE = 0>
 __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr, int bin, int binHi,
                                                   const int* __restrict__ rowIds,
                                                   const int* __restrict__ IA, const int2* __restrict__ SBL,
@@ -785,7 +838,7 @@ __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr,
                                                   const float* __restrict__ VB,
                                                   const int* __restrict__ IC, int* __restrict__ JC,
                                                   float* __restrict__ C, int* __restrict__ err,
-                                                  const int* __restrict__ rowFlops) {
+                                                  const int* __restrict__ rowFlops, int* __restrict__ pcnt) {
   __shared__ slot_t tab[16][TBL];              // (column, value) pairs
   __shared__ G16Stage st[16];
   const int tid = threadIdx.x, g = tid >> 4, gl = tid & 15;
@@ -803,8 +856,22 @@ __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr,
     // rows whose products all hit different columns (want == flops: 93-99 % of the rows this small on a power-law
     // matrix) are EXPANDED: products go straight to their position in the row, no table, no compaction.  The four
     // rows of a wave take the same path (wave-uniform control flow).
-    const bool hashRow = live && want != rowFlops[row];
+    const bool hashRow = live && (PRUNE == 2 || want != rowFlops[row]);
     if (ballot64(hashRow) == 0ull) {
+      if (PRUNE) {                                   // the row's products as a plain list in LDS, then the row rule
+        if (live) {
+          g16_walk<U, true>(st[g], gl, IA[row], IA[row + 1], SBL, VA, JB, VB, [&](bool active, int col, float v, int pos) {
+            if (active && (unsigned)pos < (unsigned)min(want, TBL)) tab[g][pos] = make_slot(col, v);
+          });
+        }
+        wave_lds_sync();
+        int nocc;
+        const int kept = prune_emit_group<16>(tab[g], (min(want, TBL) + 15) & ~15, min(want, TBL), false, live, gl,
+                                              JC + off, C + off, &nocc);
+        if (live && gl == 0) { pcnt[row] = kept; if (want > TBL) atomicOr(err, ERRF_TABLE_FULL); }
+        wave_lds_sync();
+        continue;
+      }
       if (live) {
         g16_walk<U, true>(st[g], gl, IA[row], IA[row + 1], SBL, VA, JB, VB, [&](bool active, int col, float v, int pos) {
           if (active && (unsigned)pos < (unsigned)want) { st_out(JC + off + pos, col); st_out(C + off + pos, v); }
@@ -822,6 +889,13 @@ __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr,
       });
     }
     wave_lds_sync();
+    if (PRUNE) {
+      int nocc;
+      const int kept = prune_emit_group<16>(tab[g], size, PRUNE == 2 ? -1 : want, true, live, gl, JC + off, C + off, &nocc);
+      if (live && gl == 0) { pcnt[row] = kept; if (PRUNE == 1 && nocc != want) atomicOr(err, ERRF_COUNT_MISMATCH); }
+      wave_lds_sync();
+      continue;
+    }
     int written = 0;
     for (int i0 = 0; i0 < size; i0 += 16) {
       const slot_t sv = tab[g][i0 + gl];
@@ -1207,7 +1281,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ 
   }
 }
 
-template <int NW, int TBL, int U>
+template <int NW, int TBL, int U, int PRUNE = 0>      // PRUNE: see k_num_g16
 __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ binPtr, int bin,
                                                          const int* __restrict__ rowIds,
                                                          const int* __restrict__ IA, const int2* __restrict__ SBL,
@@ -1216,8 +1290,10 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
                                                          const float* __restrict__ VB,
                                                          const int* __restrict__ IC, int* __restrict__ JC,
                                                          float* __restrict__ C, int* __restrict__ err,
-                                                         int* __restrict__ qctr, const int* __restrict__ rowFlops) {
+                                                         int* __restrict__ qctr, const int* __restrict__ rowFlops,
+                                                         int* __restrict__ pcnt) {
   __shared__ __attribute__((aligned(16))) slot_t tab[TBL];   // (column, value) pairs
+  __shared__ PruneShared<NW> ps;                 // (fused prune, several waves: the block reductions)
   __shared__ typename WalkSel<NW>::type st;
   __shared__ int qslot;
   __shared__ int emitted;                        // output positions handed out so far in this row (NW > 1)
@@ -1251,7 +1327,28 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
     }
     const int off = cur.x0;
     const int want = cur.x1 - off;                      // exact distinct count from the symbolic pass
-    if (NW == 1 && want == cur.x2) {
+    if (NW == 1 && PRUNE == 1 && want == cur.x2 && want <= TBL) {
+      // fused prune of an expanded row: its products as a plain list in LDS (no clear, no probing), then the row rule
+      for_each_product<NW, U, true>(st, cur.as, cur.ae, SBL, VA, JB, VB,
+                                    [&](const auto& act, const auto& col, const auto& val, int p0) {
+        constexpr int R = (int)(sizeof(col) / sizeof(col[0]));
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          const unsigned o = (unsigned)(p0 + u * WAVE + lane_id());
+          if (act[u] && o < (unsigned)want) tab[o] = make_slot(col[u], val[u]);
+        }
+      }, pc, err);
+      wave_lds_sync();
+      int nocc;
+      const int kept = prune_emit_group<64>(tab, (want + 63) & ~63, want, false, true, lane_id(), JC + off, C + off, &nocc);
+      if (lane_id() == 0) pcnt[cur.row] = kept;
+      wave_lds_sync();
+      cur = nxt;
+      nxt = nn; pc = pn;
+      q = qn;
+      continue;
+    }
+    if (NW == 1 && PRUNE == 0 && want == cur.x2) {
       // As many distinct columns as products: no two products of this row meet, nothing to accumulate.  The row is
       // EXPANDED: every product goes straight to the position it has in the row's own numbering -- coalesced stores,
       // no table, no clear, no compaction sweep (more than half of the products of rows up to 256 products on a
@@ -1293,7 +1390,15 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
     const int per = size / NW;
     const int lane = lane_id(), w = tid >> 6;
     if (ABL(4)) { __syncthreads(); }
-    else if (NW == 1) {
+    else if (PRUNE && NW == 1) {
+      int nocc;
+      const int kept = prune_emit_group<64>(tab, per, PRUNE == 2 ? -1 : want, true, true, lane, JC + off, C + off, &nocc);
+      if (tid == 0) { pcnt[cur.row] = kept; if (PRUNE == 1 && nocc != want) atomicOr(err, ERRF_COUNT_MISMATCH); }
+      __syncthreads();
+    } else if (PRUNE) {
+      prune_emit_block<NW, TBL / NW / WAVE>(tab, per, PRUNE == 2 ? -1 : want, ps, JC + off, C + off, pcnt + cur.row, err);
+      __syncthreads();
+    } else if (NW == 1) {
       int pos = 0;                                    // relative to the row: small 32-bit offsets for both stores
       int* const JCrow = JC + off;
       float* const Crow = C + off;
@@ -1884,35 +1989,13 @@ __global__ __launch_bounds__(256) void k_sort_long_rows(int m, const int* __rest
 
 
 // ------------------------------------------------------------------------------------------------
-// R-MCL post-step (the step right after the SpGEMM in the reference's loop):
-// per row of C: inflate (square), max, sum, thresh = clamp(0.9*avg*(1-2(max-avg)), 1e-7, max), keep v >= thresh,
-// divide the kept values by their sum, compact.  CPU: nlibs/tools/util.cc:4-69, nlibs/qrmcl.cc:96-117;
+// R-MCL post-step (the step right after the SpGEMM in the reference's loop) on a C that is
+// already in HBM: the row rule above + compaction.  CPU: nlibs/tools/util.cc:4-69, nlibs/qrmcl.cc:96-117;
 // reference GPU: nlibs/gpus/dutil.cuh:8-80 + thrust::remove (gpu_csr_kernel.cu:218-229,265-270).
 // 16 lanes per row (4 rows per wave).  Sums are 16-lane tree reductions in float, so a value that sits within an
 // ulp of the threshold can fall on the other side than in the sequential CPU loop (the reference's own GPU path
 // has the same property).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float rmcl_threshold(float avg, float mx) {
-  float ret = (float)(0.90 * avg * (1 - 2 * (mx - avg)));       // same promotions as computeThreshold (util.cc:4-9)
-  ret = (float)((ret > 1.0e-7) ? ret : 1.0e-7);
-  ret = (ret > mx) ? mx : ret;
-  return ret;
-}
-
-// reductions inside the L lanes that share a row (L = 16 or 64, aligned lane groups)
-template <int L>
-__device__ __forceinline__ float rowL_sum(float v) {
-#pragma unroll
-  for (int d = L / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, L);
-  return v;
-}
-template <int L>
-__device__ __forceinline__ float rowL_max(float v) {
-#pragma unroll
-  for (int d = L / 2; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, L));
-  return v;
-}
-
 // pass 1: inflate (squares, recomputed where needed, never stored), per-row threshold and kept sum, kept count ->
 // cnt[row].  L lanes per row: 16 for short rows, a whole wave once rows average ~100 entries (R-MCL products do);
 // four loads in flight per lane.
@@ -1947,7 +2030,7 @@ __global__ __launch_bounds__(256) void k_rmcl_stats(int m, const int* __restrict
       for (int i = 0; i < 4; ++i) { const float v = c[i] * c[i]; if (p + i * L < e && v >= th) { ks += v; ++kc; } }
     }
     ks = rowL_sum<L>(ks);
-    kc = (int)rowL_sum<L>((float)kc);
+    kc = (int)rowL_sum<L>((float)kc);                  // (< 2^24 per lane group: exact)
     if (live && gl == 0) { cnt[row] = kc; thresh[row] = th; ksum[row] = ks; }
   }
 }
@@ -1989,6 +2072,71 @@ __global__ __launch_bounds__(256) void k_rmcl_compact(int m, const int* __restri
   }
 }
 
+
+// fused path, after the numeric kernels: the kept entries sit at the front of every row's scratch range
+// [IC[row], ...), newPtr is the scan of their counts -- pack them into the new arrays
+template <int L>
+__global__ __launch_bounds__(256) void k_rmcl_move(int m, const int* __restrict__ IC, const int* __restrict__ newPtr,
+                                                    const int* __restrict__ JC, const float* __restrict__ C,
+                                                    int* __restrict__ JN, float* __restrict__ CN) {
+  constexpr int RPB = 256 / L;
+  const int gl = threadIdx.x & (L - 1);
+  for (int row = blockIdx.x * RPB + threadIdx.x / L; row < m; row += gridDim.x * RPB) {
+    const int src = IC[row], dst = newPtr[row], n = newPtr[row + 1] - dst;
+    for (int i = gl; i < n; i += L) { JN[dst + i] = JC[src + i]; CN[dst + i] = C[src + i]; }
+  }
+}
+
+// fused path, rows the numeric kernels wrote out in full (bin 8: their rows pass through LDS in several pieces): the
+// row rule from HBM / L2 by one block per row, the kept entries compacted IN PLACE to the front of the row's range.
+__global__ __launch_bounds__(256) void k_rmcl_fix_rows(const int* __restrict__ binPtr, int binLo, int binHi,
+                                                        const int* __restrict__ rowIds, const int* __restrict__ IC,
+                                                        int* __restrict__ JC, float* __restrict__ C,
+                                                        int* __restrict__ cnt) {
+  __shared__ float fred[2][4];
+  __shared__ int wcnt[4];
+  const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+  const int first = binPtr[binLo], count = binPtr[binHi] - first;
+  for (int q = blockIdx.x; q < count; q += gridDim.x) {
+    const int row = rowIds[first + q];
+    const int s = IC[row], e = IC[row + 1];
+    float mx = 0.f, sum = 0.f;
+    for (int p = s + tid; p < e; p += 256) { const float c = C[p], v = c * c; mx = fmaxf(mx, v); sum += v; }
+    mx = rowL_max<64>(mx);
+    sum = rowL_sum<64>(sum);
+    if (lane == 0) { fred[0][w] = mx; fred[1][w] = sum; }
+    __syncthreads();
+    mx = fmaxf(fmaxf(fred[0][0], fred[0][1]), fmaxf(fred[0][2], fred[0][3]));
+    sum = ((fred[1][0] + fred[1][1]) + fred[1][2]) + fred[1][3];
+    __syncthreads();
+    const float th = rmcl_threshold(sum / (float)(e - s), mx);
+    float ks = 0.f;
+    for (int p = s + tid; p < e; p += 256) { const float c = C[p], v = c * c; ks += v >= th ? v : 0.f; }
+    ks = rowL_sum<64>(ks);
+    if (lane == 0) fred[0][w] = ks;
+    __syncthreads();
+    ks = ((fred[0][0] + fred[0][1]) + fred[0][2]) + fred[0][3];
+    int out = 0;                                       // kept so far (block-uniform)
+    for (int p0 = s; p0 < e; p0 += 256) {
+      const int p = p0 + tid;
+      const float c = p < e ? C[p] : 0.f;
+      const int j = p < e ? JC[p] : 0;
+      asm volatile("" :: "v"(c), "v"(j));              // both loads have landed before the barrier: writes below may hit
+      const float v = c * c;                           // positions other lanes of this step read
+      const bool keep = p < e && v >= th;
+      const unsigned long long mk = ballot64(keep);
+      if (lane == 0) wcnt[w] = __popcll(mk);
+      __syncthreads();
+      int base = out, total = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { base += i < w ? wcnt[i] : 0; total += wcnt[i]; }
+      if (keep) { const int o = s + base + mask_rank(mk); JC[o] = j; C[o] = v / ks; }
+      out += total;
+      __syncthreads();
+    }
+    if (tid == 0) cnt[row] = out;
+  }
+}
 
 // self-test of the DPP scans / mask ranks against serial results computed by every lane
 __global__ void k_selftest(const int* __restrict__ in, int* __restrict__ bad) {

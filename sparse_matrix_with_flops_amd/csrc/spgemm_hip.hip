@@ -146,6 +146,7 @@ struct HostMirror {                 // one small device block + its pinned host 
   int slotBase[NSLOTS + 1];         // first position of every layout slot in rowIds, [NSLOTS] = m (k_bin_scan)
   unsigned long long totalP;
   unsigned long long nnzC64;
+  unsigned long long kept64;        // entries that survive the fused R-MCL prune
 };
 
 struct spgemm_handle {
@@ -416,6 +417,13 @@ static void join_streams(spgemm_handle* h) {
   }
 }
 
+#define LAUNCH_NUM(NW, TBL, grid, block, st, ...)                                                               \
+  do {                                                                                                         \
+    if (pcnt && pmode == 2) hipLaunchKernelGGL((k_num_hash<NW, TBL, 2, 2>), grid, block, 0, st, __VA_ARGS__, pcnt); \
+    else if (pcnt) hipLaunchKernelGGL((k_num_hash<NW, TBL, 2, 1>), grid, block, 0, st, __VA_ARGS__, pcnt);     \
+    else LAUNCH_U(k_num_hash, NW, TBL, grid, block, st, __VA_ARGS__, (int*)nullptr);                           \
+  } while (0)
+
 #define LAUNCH_U(KERN, NW, TBL, grid, block, st, ...)                                              \
   do {                                                                                             \
     if (h->U == 8) hipLaunchKernelGGL((KERN<NW, TBL, 8>), grid, block, 0, st, __VA_ARGS__);        \
@@ -500,7 +508,10 @@ static int launch_scan(spgemm_handle* h, int* cnt, int m, unsigned long long* dT
 
 static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
                           const int* dJB, const float* dB, int n, const int* rowIds, const int* hostBinPtr,
-                          const int* dIC, int* dJC, float* dC) {
+                          const int* dIC, int* dJC, float* dC, int* pcnt = nullptr, int pmode = 1) {
+  // pcnt != nullptr: fused R-MCL prune -- every row leaves only its kept, normalised entries at the front of its range
+  // of dJC/dC and their count in pcnt[row] (rows of bin 8 are written in full and fixed up in place right behind).
+  // pmode 2: no symbolic pass ran, dIC holds the prefix sums of the rows' product counts (bin 8 must be empty)
   const int2* sbl = h->sbl;
   const int* bp = h->dsmall->binPtr;
   int* err = &h->dsmall->err;
@@ -526,35 +537,42 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
       hipLaunchKernelGGL(k_num_bighash, dim3(blocks), dim3(BIG_THREADS), sizeof(BigHashShared), st,
                          bp, 8, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 4, h->rowFlops,
                          h->spill_blocks >= blocks ? h->spill : (int2*)nullptr, BH_SPILL, h->bhCap, h->bhMargin); }
+    if (pcnt) hipLaunchKernelGGL(k_rmcl_fix_rows, dim3(clampi(rows(8, 9), 1, cu * 8)), dim3(256), 0, st,
+                                 bp, 8, 9, rowIds, dIC, dJC, dC, pcnt);
   }
   if (rows(7, 8) > 0) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_NUM_HASH8, st);
-    LAUNCH_U(k_num_hash, 8, 8192, dim3(clampi(rows(7, 8), 1, cu * 2)), dim3(512), st, bp, 7,
+    LAUNCH_NUM(8, 8192, dim3(clampi(rows(7, 8), 1, cu * 2)), dim3(512), st, bp, 7,
              rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 5, h->rowFlops); }
   if (rows(6, 7) > 0) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_NUM_HASH4, st);
     const int* sb = h->dsmall->slotBase;
     const int* hs_ = h->mirror.slotBase;
     const int na = hs_[SLOT_H4A + 1] - hs_[SLOT_H4A], nb = hs_[SLOT_H4B + 1] - hs_[SLOT_H4B];
-    if (na > 0 && getenv("SPGEMM_H4A_WAVE")) LAUNCH_U(k_num_hash, 1, 2048, dim3(grid8(na, cu * 9)), dim3(64), st, sb, SLOT_H4A,
+    if (na > 0) LAUNCH_NUM(4, 2048, dim3(clampi(na, 1, cu * 7)), dim3(256), st, sb, SLOT_H4A,
                          rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 6, h->rowFlops);
-    else
-    if (na > 0) LAUNCH_U(k_num_hash, 4, 2048, dim3(clampi(na, 1, cu * 7)), dim3(256), st, sb, SLOT_H4A,
-                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 6, h->rowFlops);
-    if (nb > 0) LAUNCH_U(k_num_hash, 4, 4096, dim3(clampi(nb, 1, cu * 4)), dim3(256), st, sb, SLOT_H4B,
+    if (nb > 0) LAUNCH_NUM(4, 4096, dim3(clampi(nb, 1, cu * 4)), dim3(256), st, sb, SLOT_H4B,
                          rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7, h->rowFlops); }
   if (rows(5, 6) > 0) { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_NUM_HASH1, st);
     const int* sb = h->dsmall->slotBase;
     const int* hs_ = h->mirror.slotBase;
     const int na = hs_[SLOT_H1A + 1] - hs_[SLOT_H1A], nb = hs_[SLOT_H1B + 1] - hs_[SLOT_H1B];
-    if (na > 0) LAUNCH_U(k_num_hash, 1, 512, dim3(grid8(na, cu * 24)), dim3(64), st, sb, SLOT_H1A,
+    if (na > 0) LAUNCH_NUM(1, 512, dim3(grid8(na, cu * 24)), dim3(64), st, sb, SLOT_H1A,
                          rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7, h->rowFlops);
-    if (nb > 0) LAUNCH_U(k_num_hash, 1, 1024, dim3(grid8(nb, cu * 16)), dim3(64), st, sb, SLOT_H1B,
+    if (nb > 0) LAUNCH_NUM(1, 1024, dim3(grid8(nb, cu * 16)), dim3(64), st, sb, SLOT_H1B,
                          rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7, h->rowFlops); }
   if (rows(4, 5) > 0) { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_NUM_G16, st);
-    hipLaunchKernelGGL((k_num_g16<128, 4>), dim3(grid8(cdiv(rows(4, 5), 16), cu * 16)), dim3(256), 0, st,
-                       bp, 4, 5, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, h->rowFlops); }
+    if (pcnt && pmode == 2) hipLaunchKernelGGL((k_num_g16<128, 4, 2>), dim3(grid8(cdiv(rows(4, 5), 16), cu * 16)), dim3(256), 0, st,
+                                               bp, 4, 5, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, h->rowFlops, pcnt);
+    else if (pcnt) hipLaunchKernelGGL((k_num_g16<128, 4, 1>), dim3(grid8(cdiv(rows(4, 5), 16), cu * 16)), dim3(256), 0, st,
+                                      bp, 4, 5, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, h->rowFlops, pcnt);
+    else hipLaunchKernelGGL((k_num_g16<128, 4>), dim3(grid8(cdiv(rows(4, 5), 16), cu * 16)), dim3(256), 0, st,
+                            bp, 4, 5, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, h->rowFlops, (int*)nullptr); }
   if (rows(1, 4) > 0) { KTimer t(h, SPGEMM_K_NUM_SMALL4);   // 1..16 products: 16-lane flattened kernel, one round per row
-    hipLaunchKernelGGL((k_num_g16<32, 1>), dim3(grid8(cdiv(rows(1, 4), 16), cu * 16)), dim3(256), 0, h->stream,
-                       bp, 1, 4, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, h->rowFlops); }
+    if (pcnt && pmode == 2) hipLaunchKernelGGL((k_num_g16<32, 1, 2>), dim3(grid8(cdiv(rows(1, 4), 16), cu * 16)), dim3(256), 0, h->stream,
+                                               bp, 1, 4, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, h->rowFlops, pcnt);
+    else if (pcnt) hipLaunchKernelGGL((k_num_g16<32, 1, 1>), dim3(grid8(cdiv(rows(1, 4), 16), cu * 16)), dim3(256), 0, h->stream,
+                                      bp, 1, 4, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, h->rowFlops, pcnt);
+    else hipLaunchKernelGGL((k_num_g16<32, 1>), dim3(grid8(cdiv(rows(1, 4), 16), cu * 16)), dim3(256), 0, h->stream,
+                            bp, 1, 4, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, h->rowFlops, (int*)nullptr); }
   join_streams(h);
   HIPCHK(hipGetLastError());
   return SPGEMM_OK;
@@ -1071,6 +1089,113 @@ extern "C" int hip_rmcl_prune_n(spgemm_handle* h, int m, int nnz, const int* dIC
   return rmcl_prune_impl(h, m, nnz, dIC, dJC, dC, dIN, dJN, dCN, nnzN);
 }
 
+// Expansion and prune of one R-MCL iteration as ONE operator: C = A*B is never materialised.  Every numeric kernel
+// applies the row rule to the finished row while it still sits in LDS and writes only the kept, normalised entries
+// (about a quarter of the product) to the front of the row's range of a scratch C; k_rmcl_move packs them.
+// What the reference's loop does in three steps (gpu SpGEMM, inflate+threshold kernels of dutil.cuh, thrust::remove;
+// gpu_csr_kernel.cu:218-270) and hip_gpuSpMM + hip_rmcl_prune do in two.
+extern "C" int hip_rmcl_expand_prune(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, int nnzA,
+                                     const int* dIB, const int* dJB, const float* dB, int nnzB, int m, int k, int n,
+                                     int** dIN, int** dJN, float** dCN, int* nnzN) {
+  if (!dIN || !dJN || !dCN || !nnzN) return fail(SPGEMM_ERR_ARG, "output pointer is null");
+  *dIN = nullptr; *dJN = nullptr; *dCN = nullptr; *nnzN = 0;
+  if (m < 0 || k < 0 || n < 0) return fail(SPGEMM_ERR_ARG, "negative dimension m=%d k=%d n=%d", m, k, n);
+  CHK(check_common(dIA, dJA, dA, nnzA, "A"));
+  CHK(check_common(dIB, dJB, dB, nnzB, "B"));
+  if (!h) CHK(default_handle(&h));
+  HIPCHK(hipSetDevice(h->device));
+  auto two_steps = [&]() {                           // no rows, no products, or a product too large for the scratch C
+    int *cI = nullptr, *cJ = nullptr, cn = 0;
+    float* cA = nullptr;
+    int rc = spgemm_device(h, dIA, dJA, dA, nnzA, dIB, dJB, dB, nnzB, m, k, n, nullptr, &cI, &cJ, &cA, &cn);
+    if (rc) return rc;
+    rc = rmcl_prune_impl(h, m, cn, cI, cJ, cA, dIN, dJN, dCN, nnzN);
+    pool().release(cI); pool().release(cJ); pool().release(cA);
+    return rc;
+  };
+  if (m == 0) return two_steps();
+  CHK(ws_ensure(h, m));
+  int* dIC = nullptr; int* cnt = nullptr; int* dJC = nullptr; float* dC = nullptr; int* JN = nullptr; float* CN = nullptr;
+  auto cleanup = [&](int rc) {
+    for (void* q : {(void*)dIC, (void*)cnt, (void*)dJC, (void*)dC, (void*)JN, (void*)CN}) pool().release(q);
+    return rc;
+  };
+  auto hipfail = [&](const char* what) { return cleanup(fail(SPGEMM_ERR_HIP, "rmcl expand+prune: %s: %s", what, hipGetErrorString(hipGetLastError()))); };
+  if (hipSuccess != pool().alloc((void**)&dIC, sizeof(int) * ((size_t)m + 1)) ||
+      hipSuccess != pool().alloc((void**)&cnt, sizeof(int) * ((size_t)m + 1)))
+    return hipfail("device allocation failed");
+  hipStream_t s = h->stream;
+  h->sym_m = -1;
+  hipEventRecord(h->ev[0], s);
+  h->cur_rowIds = h->rowIds;
+  int rc = launch_classify(h, dIA, dJA, dIB, m, nnzA, dIC);
+  if (rc) return cleanup(rc);
+  hipEventRecord(h->ev[1], s);
+  if (hipMemcpyAsync(h->hmid, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipEventRecord(h->evMid, s) != hipSuccess)
+    return hipfail("classification copy");
+  if (hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)m + 1), s) != hipSuccess) return hipfail("memset");
+  if (hipEventSynchronize(h->evMid) != hipSuccess) return hipfail("classification");
+  const HostMirror mid = *h->hmid;
+  const unsigned long long P = mid.totalP;
+  if (P == 0 || P > (1ull << 30)) {
+    if (hipStreamSynchronize(s) != hipSuccess) return hipfail("classification");
+    cleanup(0);
+    dIC = cnt = dJC = JN = nullptr; dC = CN = nullptr;
+    return two_steps();
+  }
+  // No row beyond 4096 products (every R-MCL iteration on a sparse graph): the symbolic pass is SKIPPED.  Its only
+  // product is the exact size of every row of C, and C is not kept: the scratch rows are laid out by the rows' product
+  // counts (known from the classification), every row is hashed in a table sized by its products and the epilogue
+  // counts the distinct columns itself.  Rows of bin 8 pass through LDS in pieces and need the exact counts.
+  const bool nosym = mid.binPtr[NBINS] - mid.binPtr[NBINS - 1] == 0 && !getenv("SPGEMM_RMCL_SYMBOLIC");
+  if (nosym) {
+    if (hipMemcpyAsync(dIC, h->rowFlops, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, s) != hipSuccess) return hipfail("copy");
+  } else if ((rc = launch_symbolic(h, dIA, dJB, m, n, h->cur_rowIds, dIC))) return cleanup(rc);
+  hipEventRecord(h->ev[2], s);
+  if ((rc = launch_scan(h, dIC, m, &h->dsmall->nnzC64))) return cleanup(rc);
+  hipEventRecord(h->ev[3], s);
+  if (hipSuccess != pool().alloc((void**)&dJC, sizeof(int) * (size_t)P) ||
+      hipSuccess != pool().alloc((void**)&dC, sizeof(float) * (size_t)P))
+    return hipfail("device allocation of the scratch product failed");
+  hipEventRecord(h->ev[4], s);
+  h->mirror = mid;
+  if ((rc = launch_numeric(h, dIA, dA, dJB, dB, n, h->cur_rowIds, mid.binPtr, dIC, dJC, dC, cnt, nosym ? 2 : 1))) return cleanup(rc);
+  hipEventRecord(h->ev[5], s);
+  if ((rc = launch_scan(h, cnt, m, &h->dsmall->kept64))) return cleanup(rc);
+  if (hipMemcpyAsync(h->hsmall, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return hipfail("numeric phase");
+  h->mirror = *h->hsmall;
+  const HostMirror& hm = h->mirror;
+  if (hm.err) return cleanup(fail(SPGEMM_ERR_INTERNAL, "device invariant broken (flags=%d)", hm.err));
+  spgemm_stats& st = h->stats;
+  st.total_flops = (long long)hm.totalP;
+  st.nnzC = nosym ? -1 : (int)std::min<unsigned long long>(hm.nnzC64, 0x7fffffffULL);   // not computed without the symbolic pass
+  for (int b = 0; b < NBINS; ++b) st.bin_rows[b] = hm.binPtr[b + 1] - hm.binPtr[b];
+  hipEventElapsedTime(&st.ms_classify, h->ev[0], h->ev[1]);
+  hipEventElapsedTime(&st.ms_symbolic, h->ev[1], h->ev[2]);
+  hipEventElapsedTime(&st.ms_scan_alloc, h->ev[2], h->ev[4]);
+  hipEventElapsedTime(&st.ms_numeric, h->ev[4], h->ev[5]);
+  hipEventElapsedTime(&st.ms_total, h->ev[0], h->ev[5]);
+  collect_kernel_times(h, true);
+  grow_bitmaps(h, n);
+  const int nz = (int)hm.kept64;                     // <= nnz(C) <= P <= 2^30
+  if (hipSuccess != pool().alloc((void**)&JN, sizeof(int) * (size_t)std::max(nz, 1)) ||
+      hipSuccess != pool().alloc((void**)&CN, sizeof(float) * (size_t)std::max(nz, 1)))
+    return hipfail("device allocation failed");
+  if (nz > 0) {
+    const bool wide = nz >= 96ll * m;
+    if (wide) hipLaunchKernelGGL(k_rmcl_move<64>, dim3(clampi(cdiv(m, 4), 1, h->numCU * 32)), dim3(256), 0, s, m, dIC, cnt, dJC, dC, JN, CN);
+    else hipLaunchKernelGGL(k_rmcl_move<16>, dim3(clampi(cdiv(m, 16), 1, h->numCU * 16)), dim3(256), 0, s, m, dIC, cnt, dJC, dC, JN, CN);
+    if (hipGetLastError() != hipSuccess) return hipfail("move launch");
+  }
+  if (hipStreamSynchronize(s) != hipSuccess) return hipfail("move");
+  pool().release(dIC); pool().release(dJC); pool().release(dC);
+  *dIN = cnt; *dJN = JN; *dCN = CN; *nnzN = nz;
+  return SPGEMM_OK;
+}
+
 extern "C" int hip_gpuRmclIter(int maxIter, int rows, int cols, const int* gIA, const int* gJA, const float* gA, int gnnz,
                                const int* tIA, const int* tJA, const float* tA, int tnnz, int** oIA, int** oJA,
                                float** oA, int* onnz) {
@@ -1093,14 +1218,9 @@ extern "C" int hip_gpuRmclIter(int maxIter, int rows, int cols, const int* gIA, 
 #undef UP
   int curnnz = tnnz;
   for (int it = 0; it < maxIter; ++it) {
-    int *cI = nullptr, *cJ = nullptr, cn = 0;
-    float* cA = nullptr;
-    if ((rc = hip_gpuSpMM(h, dgI, dgJ, dgA, gnnz, dtI, dtJ, dtA, curnnz, rows, cols, cols, &cI, &cJ, &cA, &cn))) return cleanup(rc);
     int *nI = nullptr, *nJ = nullptr, nn = 0;
     float* nA = nullptr;
-    rc = hip_rmcl_prune_n(h, rows, cn, cI, cJ, cA, &nI, &nJ, &nA, &nn);
-    pool().release(cI); pool().release(cJ); pool().release(cA);
-    if (rc) return cleanup(rc);
+    if ((rc = hip_rmcl_expand_prune(h, dgI, dgJ, dgA, gnnz, dtI, dtJ, dtA, curnnz, rows, cols, cols, &nI, &nJ, &nA, &nn))) return cleanup(rc);
     pool().release(dtI); pool().release(dtJ); pool().release(dtA);
     dtI = nI; dtJ = nJ; dtA = nA; curnnz = nn;
   }

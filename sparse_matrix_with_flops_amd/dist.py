@@ -111,18 +111,22 @@ class HipEngine:
                                           A["rows"], A["cols"], B["cols"])
         return DeviceCSR(ic, jc, cv, A["rows"], B["cols"], nnz)
 
-    def expand_prune(self, A, B):
-        """One R-MCL step on this rank's rows: C = A*B (hip_gpuSpMM), then inflate/prune/normalise + compaction
-        (hip_rmcl_prune), all on the device.  Returns torch tensors (rowPtr[rows+1], colInd, values)."""
+    def expand_prune(self, A, B, fused=True):
+        """One R-MCL step on this rank's rows, all on the device: prune(A*B).  fused: hip_rmcl_expand_prune (the row
+        rule applied inside the numeric kernels, the product never reaches HBM); otherwise hip_gpuSpMM followed by
+        hip_rmcl_prune.  Returns torch tensors (rowPtr[rows+1], colInd, values)."""
         self.sync()
-        ic, jc, cv, nnzc = hs.gpu_spmm_raw(self.handle, _ptr(A["rowPtr"]), _ptr(A["colInd"]), _ptr(A["values"]), A["nnz"],
-                                        _ptr(B["rowPtr"]), _ptr(B["colInd"]), _ptr(B["values"]), B["nnz"],
-                                        A["rows"], A["cols"], B["cols"])
-        try:
-            pi, pj, pv, nn = hs.rmcl_prune_raw(self.handle, A["rows"], ic, jc, cv, nnz=nnzc)
-        finally:
-            for p in (ic, jc, cv):
-                hs.dev_free(p)
+        args = (_ptr(A["rowPtr"]), _ptr(A["colInd"]), _ptr(A["values"]), A["nnz"],
+                _ptr(B["rowPtr"]), _ptr(B["colInd"]), _ptr(B["values"]), B["nnz"], A["rows"], A["cols"], B["cols"])
+        if fused:
+            pi, pj, pv, nn = hs.rmcl_expand_prune_raw(self.handle, *args)
+        else:
+            ic, jc, cv, nnzc = hs.gpu_spmm_raw(self.handle, *args)
+            try:
+                pi, pj, pv, nn = hs.rmcl_prune_raw(self.handle, A["rows"], ic, jc, cv, nnz=nnzc)
+            finally:
+                for p in (ic, jc, cv):
+                    hs.dev_free(p)
         try:
             rp = self.empty(A["rows"] + 1, torch.int32)
             ci = self.empty(max(nn, 1), torch.int32)

@@ -35,7 +35,7 @@ EXPORTS = [
     "hip_gpuFlopsClassify", "hip_sgpuSpMM", "hip_csr_sort_rows", "spgemm_hip_selftest",
     "hip_spgemm_symbolic", "hip_spgemm_numeric", "hip_csr_row_flops", "spgemm_hip_kernel_name",
     "hip_rmcl_prune", "hip_gpuRmclIter", "hip_coo_to_csr", "hip_flopsStats", "spgemm_hip_set_kernel_timing",
-    "hip_rmcl_prune_n", "spgemm_hip_pool_cached_bytes", "hip_nnzStats", "hip_resultsComparison",
+    "hip_rmcl_prune_n", "hip_rmcl_expand_prune", "spgemm_hip_pool_cached_bytes", "hip_nnzStats", "hip_resultsComparison",
 ]
 
 
@@ -106,6 +106,8 @@ def lib():
         L.spgemm_hip_memcpy_d2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.hip_rmcl_prune.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + \
             [C.POINTER(C.c_void_p)] * 3 + [_I]
+        L.hip_rmcl_expand_prune.argtypes = [C.c_void_p] + dev_in + dev_in + [C.c_int, C.c_int, C.c_int] + \
+            [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(C.c_int)]
         L.hip_rmcl_prune_n.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + \
             [C.POINTER(C.c_void_p)] * 3 + [_I]
         L.spgemm_hip_pool_cached_bytes.argtypes = [C.c_int, C.POINTER(C.c_size_t)]
@@ -326,6 +328,17 @@ def rmcl_prune_raw(handle, m, IC, JC, CV, nnz=None):
     else:
         _check(lib().hip_rmcl_prune_n(hp, int(m), int(nnz), C.c_void_p(IC), C.c_void_p(JC), C.c_void_p(CV),
                                       C.byref(i_), C.byref(j_), C.byref(c_), C.byref(n_)), "hip_rmcl_prune_n")
+    return i_.value, j_.value, c_.value, n_.value
+
+
+def rmcl_expand_prune_raw(handle, IA, JA, VA, nnzA, IB, JB, VB, nnzB, m, k, n):
+    """hip_rmcl_expand_prune on raw device pointers: prune(A*B) of one R-MCL iteration without materialising the product.
+    Returns (IN, JN, CN, nnzN) in pool arrays; release the three with dev_free."""
+    i_, j_, c_, n_ = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+    _check(lib().hip_rmcl_expand_prune(handle.ptr if handle else None, C.c_void_p(IA), C.c_void_p(JA), C.c_void_p(VA),
+                                       int(nnzA), C.c_void_p(IB), C.c_void_p(JB), C.c_void_p(VB), int(nnzB),
+                                       int(m), int(k), int(n), C.byref(i_), C.byref(j_), C.byref(c_), C.byref(n_)),
+           "hip_rmcl_expand_prune")
     return i_.value, j_.value, c_.value, n_.value
 
 

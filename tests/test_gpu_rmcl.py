@@ -45,20 +45,92 @@ def _graph(m, seed):
     return po.rmcl_init(A.rows, A.cols, A.colInd, ri, np.ones_like(A.values))     # transpose + self loops + row-normalise
 
 
-def _device_steps(Mt, iters):
-    """The device-resident loop one step at a time (hip_gpuSpMM + hip_rmcl_prune per step): yields (k, Mt_k, Mt_k+1)."""
+def _device_steps(Mt, iters, fused=True):
+    """The device-resident loop one step at a time: yields (k, Mt_k, Mt_k+1).  fused: hip_rmcl_expand_prune per step
+    (what hip_gpuRmclIter and ShardedRMCL run); otherwise hip_gpuSpMM + hip_rmcl_prune."""
     import torch
     from sparse_matrix_with_flops_amd.dist import HipEngine, make_matrix
     eng = HipEngine(0)
     Mg = make_matrix(eng, Mt.rowPtr, Mt.colInd, Mt.values, Mt.rows, Mt.cols)
     cur_dev, cur_host = Mg, Mt
     for k in range(iters):
-        rp, ci, v = eng.expand_prune(Mg, cur_dev)
+        rp, ci, v = eng.expand_prune(Mg, cur_dev, fused=fused)
         torch.cuda.synchronize()
         nxt_host = po.CSRHost(rp.cpu().numpy(), ci.cpu().numpy(), v.cpu().numpy(), Mt.rows, Mt.cols)
         yield k, cur_host, nxt_host
         cur_dev = {"rowPtr": rp, "colInd": ci, "values": v, "rows": Mt.rows, "cols": Mt.cols, "nnz": int(ci.numel())}
         cur_host = nxt_host
+
+
+def _ragged(rows, cols, lens, seed, pools=None):
+    """CSR whose row i has lens[i] distinct random columns (unsorted) and values in [0.25, 1.25); pools: {row: array of
+    the columns that row draws from}."""
+    rng = np.random.default_rng(seed)
+    rp = np.zeros(rows + 1, dtype=np.int32)
+    np.cumsum(lens, out=rp[1:])
+    ci = np.empty(int(rp[-1]), dtype=np.int32)
+    for i in range(rows):
+        ci[rp[i]:rp[i + 1]] = rng.choice(cols if not pools or i not in pools else pools[i], size=int(lens[i]), replace=False)
+    v = (rng.random(len(ci)) + 0.25).astype(np.float32)
+    return po.CSRHost(rp, ci, v, rows, cols)
+
+
+@pytest.mark.parametrize("n,big", [(6000, True), (300000, True), (6000, False), (300000, False)])
+def test_fused_expand_prune_every_kernel(n, big):
+    """hip_rmcl_expand_prune on a rectangular product whose rows land in EVERY bin, with duplicate-free rows (list
+    staging) and colliding rows (hash tables) in each: one step against the oracle.
+    big: rows beyond 4096 products exist (n = 300000 sends them through the hash kernel and its multi-pass rows,
+    n = 6000 through the rank kernel) -> the operator runs the symbolic pass and fixes those rows up in place;
+    not big: bins 0..7 only -> the operator skips the symbolic pass (rows laid out by product counts)."""
+    import torch
+    from sparse_matrix_with_flops_amd.dist import HipEngine, make_matrix
+    rng = np.random.default_rng(5)
+    m, k = 2500, 4000
+    pools = {}
+    if big:
+        blen = rng.choice([0, 1, 2, 3, 5, 9, 20, 70, 200, 900], size=k, p=[.05, .2, .2, .15, .15, .1, .08, .04, .02, .01])
+        alen = rng.choice([0, 1, 2, 4, 8, 20, 60, 150, 400, 1500], size=m, p=[.03, .1, .15, .2, .2, .15, .1, .04, .02, .01])
+    else:
+        blen = rng.choice([0, 1, 2, 3, 5, 9, 20, 66], size=k, p=[.05, .2, .2, .15, .15, .1, .1, .05])
+        alen = rng.choice([0, 1, 2, 4, 8, 20, 40, 60], size=m, p=[.03, .1, .15, .2, .2, .15, .1, .07])
+        longB = np.nonzero(blen == 66)[0]
+        for i in range(0, m, 50):                                         # rows of 45..60 long B rows: 2970..3960 products
+            alen[i] = 45 + (i // 50) % 16
+            pools[i] = longB
+    A = _ragged(m, k, alen, 11, pools)
+    B = _ragged(k, n, blen, 12)
+    eng = HipEngine(0)
+    dA = make_matrix(eng, A.rowPtr, A.colInd, A.values, A.rows, A.cols)
+    dB = make_matrix(eng, B.rowPtr, B.colInd, B.values, B.rows, B.cols)
+    rp, ci, v = eng.expand_prune(dA, dB, fused=True)
+    torch.cuda.synchronize()
+    st = eng.stats()
+    assert all(r > 0 for r in st["bin_rows"][:8]) and (st["bin_rows"][8] > 0) == big, st["bin_rows"]
+    assert (st["nnzC"] == -1) == (not big)                                # -1: no symbolic pass ran
+    got = po.CSRHost(rp.cpu().numpy(), ci.cpu().numpy(), v.cpu().numpy(), m, n)
+    # rows of more than 512 product entries: the kept sum alone adds thousands of float32 terms in another order than
+    # the sequential CPU loop (measured worst 5.6e-6 on rows of ~6000 entries); all other rows at the 3e-6 of the step
+    ndiff, ties, want = assert_rmcl_step(got, A, B, what=f"fused step, n={n}", rel_long=(512, 2e-5))
+    print(f"n={n}: bins {st['bin_rows']}, {ndiff} rows differ ({ties} tie rows), nnz {got.nnz} vs {want.nnz}")
+    # and the two-step path agrees with the same oracle on the same inputs
+    rp2, ci2, v2 = eng.expand_prune(dA, dB, fused=False)
+    torch.cuda.synchronize()
+    got2 = po.CSRHost(rp2.cpu().numpy(), ci2.cpu().numpy(), v2.cpu().numpy(), m, n)
+    assert_rmcl_step(got2, A, B, what=f"two-step, n={n}", rel_long=(512, 2e-5))
+
+
+def test_fused_and_two_step_loops_agree(monkeypatch):
+    """Three iterations of the loop three ways on the same graph -- fused without the symbolic pass (what the loop runs:
+    no row of this graph passes 4096 products), fused with it (SPGEMM_RMCL_SYMBOLIC), and hip_gpuSpMM + hip_rmcl_prune --
+    every step of each against the oracle."""
+    Mt = _graph(20000, 91)
+    for fused, sym in ((True, False), (True, True), (False, False)):
+        if sym:
+            monkeypatch.setenv("SPGEMM_RMCL_SYMBOLIC", "1")
+        else:
+            monkeypatch.delenv("SPGEMM_RMCL_SYMBOLIC", raising=False)
+        for k, cur, nxt in _device_steps(Mt, 3, fused=fused):
+            assert_rmcl_step(nxt, Mt, cur, what=f"fused={fused} symbolic={sym} iteration {k + 1}")
 
 
 def test_rmcl_synthetic_graph_three_iterations():
