@@ -99,21 +99,22 @@ __global__ void k_missing_flags(int rows, const unsigned char* __restrict__ hasD
   if (r < rows) miss[r] = hasDiag[r] ? 0 : 1;
 }
 
-// keys of the original entries and of the appended self loops; payload = position in the (extended) input
-__global__ void k_make_keys(int nnz, int rows, int cols, const int* __restrict__ ri, const int* __restrict__ ci,
-                            const int* __restrict__ missPos, const int* __restrict__ miss,
-                            unsigned long long* __restrict__ keys, int* __restrict__ idx, int total) {
+// keys of the original entries and of the appended self loops: (row << colBits) | col, same order as row * cols + col
+// without a 64-bit division on the way back.  The payload that travels with a key through the (stable) sort is the
+// entry's VALUE: the emit step then reads keys and values in order instead of gathering values through an index.
+__global__ void k_make_keys(int nnz, int rows, int colBits, const int* __restrict__ ri, const int* __restrict__ ci,
+                            const float* __restrict__ val, const int* __restrict__ missPos, const int* __restrict__ miss,
+                            unsigned long long* __restrict__ keys, int* __restrict__ payload) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nnz) {
-    keys[i] = (unsigned long long)(unsigned)ri[i] * (unsigned long long)(unsigned)cols + (unsigned)ci[i];
-    idx[i] = i;
+    keys[i] = ((unsigned long long)(unsigned)ri[i] << colBits) | (unsigned)ci[i];
+    payload[i] = __float_as_int(val[i]);
   }
   if (miss && i < rows && miss[i]) {            // self loop (i,i,1.0) appended behind the input, in row order
     const int p = nnz + missPos[i];
-    keys[p] = (unsigned long long)(unsigned)i * (unsigned long long)(unsigned)cols + (unsigned)i;
-    idx[p] = p;
+    keys[p] = ((unsigned long long)(unsigned)i << colBits) | (unsigned)i;
+    payload[p] = __float_as_int(1.0f);
   }
-  (void)total;
 }
 
 __global__ void k_heads(int n, const unsigned long long* __restrict__ keys, int dedupe, int* __restrict__ head) {
@@ -121,22 +122,34 @@ __global__ void k_heads(int n, const unsigned long long* __restrict__ keys, int 
   if (i < n) head[i] = (!dedupe || i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
 }
 
-// one thread per output entry (= head of a run of equal keys): column, summed value, row count
-__global__ void k_emit(int n, int nnzIn, int cols, const unsigned long long* __restrict__ keys, const int* __restrict__ idx,
-                       const int* __restrict__ head, const int* __restrict__ pos, const float* __restrict__ val,
-                       int dedupe, int useAbs, int* __restrict__ JA, float* __restrict__ A, int* __restrict__ rowCnt) {
+// one thread per output entry (= head of a run of equal keys): column and summed value (input order inside a run)
+__global__ void k_emit(int n, int colBits, const unsigned long long* __restrict__ keys, const int* __restrict__ payload,
+                       const int* __restrict__ head, const int* __restrict__ pos,
+                       int dedupe, int useAbs, int* __restrict__ JA, float* __restrict__ A) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !head[i]) return;
   const unsigned long long k = keys[i];
-  const int src = idx[i];
-  float s = src < nnzIn ? val[src] : 1.0f;       // appended self loops carry 1.0
+  float s = __int_as_float(payload[i]);
   if (dedupe)
-    for (int j = i + 1; j < n && keys[j] == k; ++j) { const int sj = idx[j]; s += sj < nnzIn ? val[sj] : 1.0f; }
-  const int r = (int)(k / (unsigned long long)(unsigned)cols), c = (int)(k - (unsigned long long)r * (unsigned)cols);
+    for (int j = i + 1; j < n && keys[j] == k; ++j) s += __int_as_float(payload[j]);
   const int o = pos[i];
-  JA[o] = c;
+  JA[o] = (int)(k & ((1ull << colBits) - 1ull));
   A[o] = useAbs ? fabsf(s) : s;
-  atomicAdd(&rowCnt[r], 1);                      // integer counts: the result does not depend on the order
+}
+
+// rowPtr straight from the sorted keys: IA[r] = output position of the first key of row r or later (binary search, one
+// thread per row; pos[n] = number of output entries).  No per-entry atomics, no scan, empty rows need no special case.
+__global__ void k_row_starts(int rows, int n, int colBits, const unsigned long long* __restrict__ keys,
+                             const int* __restrict__ pos, int* __restrict__ IA) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > rows) return;
+  const unsigned long long want = (unsigned long long)(unsigned)r << colBits;
+  int lo = 0, hi = n;                            // first index with keys[idx] >= want
+  while (lo < hi) {
+    const int mid = (int)(((long long)lo + hi) >> 1);
+    if (keys[mid] < want) lo = mid + 1; else hi = mid;
+  }
+  IA[r] = pos[lo];
 }
 
 __global__ void k_row_normalise(int rows, const int* __restrict__ IA, float* __restrict__ A) {
@@ -182,7 +195,9 @@ extern "C" int hip_coo_to_csr(spgemm_handle* h, int rows, int cols, int nnz, con
 #define COO_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return cleanup(fail(SPGEMM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
   const int T = 256;
   auto grid = [&](long long n) { return dim3((unsigned)std::max<long long>(1, (n + T - 1) / T)); };
-  const int keyBits = std::max(1, 64 - __builtin_clzll((unsigned long long)std::max(1, rows) * (unsigned long long)std::max(1, cols)));
+  auto bits_of = [](int maxval) { return maxval > 0 ? 32 - __builtin_clz((unsigned)maxval) : 0; };
+  const int colBits = std::max(1, bits_of(cols - 1));      // key = (row << colBits) | col
+  const int keyBits = std::max(1, bits_of(rows - 1) + colBits);
   // scratch of the scans: tile sums of the longest array scanned below (entries, rows + 1, or 256 x radix blocks)
   const long long nblkMax = (maxTotal + coo::RS_TILE - 1) / coo::RS_TILE + 1;
   const long long longest = std::max<long long>(std::max<long long>(maxTotal, (long long)rows + 1), nblkMax * coo::RS_RADIX) + 1;
@@ -239,8 +254,8 @@ extern "C" int hip_coo_to_csr(spgemm_handle* h, int rows, int cols, int nnz, con
   COO_ALLOC(keyB, sizeof(unsigned long long) * (size_t)total);
   COO_ALLOC(idxA, sizeof(int) * (size_t)total);
   COO_ALLOC(idxB, sizeof(int) * (size_t)total);
-  hipLaunchKernelGGL(coo::k_make_keys, grid(std::max(nnz, loops ? rows : 0)), dim3(T), 0, s, nnz, rows, cols, dRow, dCol,
-                     missPos, loops ? miss : (int*)nullptr, keyA, idxA, total);
+  hipLaunchKernelGGL(coo::k_make_keys, grid(std::max(nnz, loops ? rows : 0)), dim3(T), 0, s, nnz, rows, colBits, dRow, dCol,
+                     dVal, missPos, loops ? miss : (int*)nullptr, keyA, idxA);
   {
     const int nblk = cdiv(total, coo::RS_TILE);
     COO_ALLOC(bhist, sizeof(int) * ((size_t)nblk * coo::RS_RADIX + 1));
@@ -266,9 +281,9 @@ extern "C" int hip_coo_to_csr(spgemm_handle* h, int rows, int cols, int nnz, con
   // (4) emit columns / values / row counts, scan the counts, optional row normalisation
   COO_ALLOC(JA, sizeof(int) * (size_t)std::max(outN, 1));
   COO_ALLOC(A, sizeof(float) * (size_t)std::max(outN, 1));
-  hipLaunchKernelGGL(coo::k_emit, grid(total), dim3(T), 0, s, total, nnz, cols, keyB, idxB, head, pos, dVal, dedupe,
-                     (flags & SPGEMM_COO_ABS) ? 1 : 0, JA, A, IA);
-  COO_HIP(scan_inplace(IA, rows, nullptr));               // counts -> rowPtr, IA[rows] = nnz
+  hipLaunchKernelGGL(coo::k_emit, grid(total), dim3(T), 0, s, total, colBits, keyB, idxB, head, pos, dedupe,
+                     (flags & SPGEMM_COO_ABS) ? 1 : 0, JA, A);
+  hipLaunchKernelGGL(coo::k_row_starts, grid((long long)rows + 1), dim3(T), 0, s, rows, total, colBits, keyB, pos, IA);
   if ((flags & SPGEMM_COO_ROW_NORMALISE) && rows > 0)
     hipLaunchKernelGGL(coo::k_row_normalise, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, rows, IA, A);
   COO_HIP(hipGetLastError());

@@ -1498,9 +1498,15 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sym_big(const int* __restrict__
   BigSymShared& sh = *reinterpret_cast<BigSymShared*>(smem_raw);
   const int tid = threadIdx.x;
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
-  for (int q = next_row(qctr, &sh.red[0]); q < count; q = next_row(qctr, &sh.red[0])) {
-    const int row = rowIds[first + q];
-    const int as = IA[row], ae = IA[row + 1];
+  // the next row is dequeued and its metadata requested before this row's work starts: the dependent chain
+  // queue -> rowIds -> IA (three memory round trips) hides behind the row instead of preceding it
+  int q = next_row(qctr, &sh.red[0]);
+  RowMeta cur = load_meta_sym(rowIds + first, q, count, IA, IA);
+  while (q < count) {
+    const int qn = next_row(qctr, &sh.red[0]);
+    const RowMeta nxt = load_meta_sym(rowIds + first, qn, count, IA, IA);
+    const int row = cur.row;
+    const int as = cur.as, ae = cur.ae;
     int total = 0;
     for (int w0 = 0; w0 < n; w0 += SYM_WC) {
       const int wc = min(SYM_WC, n - w0);
@@ -1530,6 +1536,8 @@ __global__ __launch_bounds__(BIG_THREADS) void k_sym_big(const int* __restrict__
       __syncthreads();
     }
     if (tid == 0) IC[row] = total;
+    cur = nxt;
+    q = qn;
   }
 }
 
@@ -1668,17 +1676,20 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
   int2* const park = spill ? spill + (size_t)blockIdx.x * (size_t)spillCap : nullptr;
   if (tid < WAVE) sh.st.dummy[tid] = DUMMY_SLOT;
-  for (int q = next_row(qctr, &sh.red[0]); q < count; q = next_row(qctr, &sh.red[0])) {
-    const int row = rowIds[first + q];
-    const int as = IA[row], ae = IA[row + 1];
-    const int outBase = IC[row];
-    const int outEnd = IC[row + 1];
+  int q = next_row(qctr, &sh.red[0]);                 // one row ahead, as in k_sym_big
+  RowMeta cur = load_meta_num(rowIds + first, q, count, IA, IC, rowFlops);
+  while (q < count) {
+    const int qn = next_row(qctr, &sh.red[0]);
+    const RowMeta nxt = load_meta_num(rowIds + first, qn, count, IA, IC, rowFlops);
+    const int as = cur.as, ae = cur.ae;
+    const int outBase = cur.x0;
+    const int outEnd = cur.x1;
     const int want = outEnd - outBase;
     const unsigned npass = (unsigned)((want + bhCap - 1) / bhCap);
     // class c >= 1 parks in its own region of `stride` pairs: the expected class size (the classes are a hash of the
     // column, so products/npass) plus a margin.  A class that outgrows its region raises sh.ovf and the row is redone
     // the slow way (one walk per pass) -- rare, and never wrong.
-    const int flops = rowFlops[row];
+    const int flops = cur.x2;
     const int stride = (int)min((long long)flops, (long long)flops * marginPct / (100ll * (long long)npass) + 256ll);
     const bool canSpill = npass > 1 && npass <= (unsigned)BH_MAXCLS && park != nullptr &&
                           (long long)(npass - 1) * stride <= (long long)spillCap;
@@ -1767,6 +1778,8 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
     }
     if (tid == 0 && sh.emitted != want) atomicOr(err, ERRF_COUNT_MISMATCH);
     __syncthreads();
+    cur = nxt;
+    q = qn;
   }
 }
 
