@@ -563,10 +563,28 @@ __global__ __launch_bounds__(256) void k_entry_lens(int nnzA, const int* __restr
   }
 }
 
-// SBL != nullptr: lengths come from K1a's records (coalesced); otherwise gathered through JA -> IB
+// inclusive +-scan of 64-bit values over the wave (both halves travel through the same DPP moves)
+__device__ __forceinline__ unsigned long long wave_incl_add_u64(unsigned long long v) {
+#define SMF_DPP64_STEP(ctrl, rowmask)                                                                          \
+  {                                                                                                             \
+    const unsigned lo = (unsigned)SMF_DPP((int)(unsigned)v, ctrl, rowmask, 0);                                   \
+    const unsigned hi = (unsigned)SMF_DPP((int)(unsigned)(v >> 32), ctrl, rowmask, 0);                           \
+    v += ((unsigned long long)hi << 32) | lo;                                                                   \
+  }
+  SMF_DPP64_STEP(0x111, 0xf) SMF_DPP64_STEP(0x112, 0xf) SMF_DPP64_STEP(0x114, 0xf) SMF_DPP64_STEP(0x118, 0xf)
+  SMF_DPP64_STEP(0x142, 0xa) SMF_DPP64_STEP(0x143, 0xc)
+#undef SMF_DPP64_STEP
+  return v;
+}
+
+// K1: one wave owns 64 consecutive rows = ONE contiguous range of A entries.  The wave walks that range 64 entries at a
+// time, fully coalesced: entry -> column -> {B-row start, length} (the record of K1a, written here when SBL != nullptr:
+// the two kernels are one), an inclusive scan of the 64 lengths, and every row takes the difference of the scan values
+// at its two ends (two cross-lane reads).  No per-lane walk of its own row (64 different lines per load) and no serial
+// finishing of long rows.  CHK chunks are in flight together (their JA -> IB chains are independent).
 __global__ __launch_bounds__(K1_THREADS) void k_row_flops(
     int m, const int* __restrict__ IA, const int* __restrict__ JA, const int* __restrict__ IB,
-    const int2* __restrict__ SBL,
+    int2* __restrict__ SBL, int sblCap,
     int* __restrict__ rowFlops, unsigned char* __restrict__ binId, int* __restrict__ blockHist,
     unsigned long long* __restrict__ blockP, int* __restrict__ IC) {
   __shared__ int hist[NSLOTS];
@@ -576,30 +594,29 @@ __global__ __launch_bounds__(K1_THREADS) void k_row_flops(
   if (tid == 0) psum = 0;
   __syncthreads();
   const int r = blockIdx.x * K1_THREADS + tid;
-  int rs = 0, re = 0;
-  if (r < m) { rs = IA[r]; re = IA[r + 1]; }
+  const int rs = IA[min(r, m)], re = IA[min(r + 1, m)];      // rows past the end: empty, at the end of the range
+  const int s = __builtin_amdgcn_readlane(rs, 0), e = __builtin_amdgcn_readlane(re, 63);
   unsigned long long f = 0;
-  if (SBL) {
+  constexpr int CHK = 4;
+  for (int c0 = s; c0 < e; c0 += CHK * WAVE) {
+    int j[CHK];
+    int2 be[CHK];
 #pragma unroll
-    for (int t = 0; t < FL_SHORT; ++t) f += rs + t < re ? (unsigned)SBL[rs + t].y : 0u;
-  } else {
-    int js[FL_SHORT];                                 // all JA loads first, then all IB loads: two round trips
+    for (int i = 0; i < CHK; ++i) { const int p = c0 + i * WAVE + lane; j[i] = p < e ? JA[p] : -1; }
 #pragma unroll
-    for (int t = 0; t < FL_SHORT; ++t) js[t] = rs + t < re ? JA[rs + t] : -1;
+    for (int i = 0; i < CHK; ++i) be[i] = j[i] >= 0 ? make_int2(IB[j[i]], IB[j[i] + 1]) : make_int2(0, 0);
 #pragma unroll
-    for (int t = 0; t < FL_SHORT; ++t) if (js[t] >= 0) f += (unsigned)(IB[js[t] + 1] - IB[js[t]]);
-  }
-  // long rows: the wave takes them one by one
-  unsigned long long longMask = ballot64(re - rs > FL_SHORT);
-  while (longMask) {
-    const int src = __ffsll((long long)longMask) - 1;
-    longMask &= longMask - 1;
-    const int s = __shfl(rs, src, 64) + FL_SHORT, e = __shfl(re, src, 64);
-    unsigned long long part = 0;
-    if (SBL) { for (int p = s + lane; p < e; p += WAVE) part += (unsigned)SBL[p].y; }
-    else { for (int p = s + lane; p < e; p += WAVE) { const int j = JA[p]; part += (unsigned)(IB[j + 1] - IB[j]); } }
-    part = wave_sum_u64(part);
-    if (lane == src) f += part;
+    for (int i = 0; i < CHK; ++i) {
+      const int cb = c0 + i * WAVE;                           // wave-uniform
+      if (cb >= e) break;
+      const int len = max(be[i].y - be[i].x, 0);
+      if (SBL && j[i] >= 0 && cb + lane < sblCap) SBL[cb + lane] = make_int2(be[i].x, len);
+      const unsigned long long incl = wave_incl_add_u64((unsigned long long)(unsigned)len);
+      const int a = min(max(rs - cb, 0), WAVE), b = min(max(re - cb, 0), WAVE);   // this row's part of the chunk: [a, b)
+      const unsigned long long hiP = __shfl(incl, max(b - 1, 0), WAVE);
+      const unsigned long long loP = __shfl(incl, max(a - 1, 0), WAVE);
+      if (b > a) f += hiP - (a > 0 ? loP : 0ull);
+    }
   }
   int b = -1;
   if (r < m) {

@@ -439,12 +439,9 @@ static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, con
   HIPCHK(hipMemsetAsync(h->dsmall, 0, sizeof(HostMirror), h->stream));
   if (nnzA >= 0) CHK(ws_ensure_entries(h, nnzA));
   if (m > 0) {
-    { KTimer t(h, SPGEMM_K_ROW_FLOPS);
-      if (nnzA > 0)
-        hipLaunchKernelGGL(k_entry_lens, dim3(clampi(cdiv(nnzA, 256), 1, h->numCU * 32)), dim3(256), 0, h->stream, (int)nnzA,
-                           dJA, dIB, h->sbl);
+    { KTimer t(h, SPGEMM_K_ROW_FLOPS);           // also writes the per-entry records h->sbl when nnz(A) is known
       hipLaunchKernelGGL(k_row_flops, dim3(nblk), dim3(K1_THREADS), 0, h->stream, m, dIA, dJA, dIB,
-                         nnzA >= 0 ? h->sbl : (const int2*)nullptr, h->rowFlops,
+                         nnzA >= 0 ? h->sbl : (int2*)nullptr, (int)std::max(nnzA, 0ll), h->rowFlops,
                          h->binId, h->blockHist, h->blockP, dIC); }
     { KTimer t(h, SPGEMM_K_BIN_SCAN);
       hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, h->stream, nblk, h->blockHist, h->blockOff,
