@@ -848,7 +848,8 @@ __global__ __launch_bounds__(256) void k_sym_g16(const int* __restrict__ binPtr,
 }
 
 // PRUNE: 0 plain product; 1 fused R-MCL prune, IC = exact row pointers of the product (symbolic pass ran); 2 fused prune
-// WITHOUT a symbolic pass: IC = prefix sums of the rows' product counts (an upper bound of every row), every row is hashed
+// WITHOUT a symbolic pass: IC = prefix sums of the rows' product counts (an upper bound of every row; rows of bin 8, which
+// these kernels do not see, contribute their exact counts), every row is hashed
 // in a table sized by its products and the distinct columns are counted by the epilogue itself.
 template <int TBL, int U, int PRUNE = 0>
 __global__ __launch_bounds__(256) void k_num_g16(const int* __restrict__ binPtr, int bin, int binHi,

@@ -508,7 +508,8 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
                           const int* dIC, int* dJC, float* dC, int* pcnt = nullptr, int pmode = 1) {
   // pcnt != nullptr: fused R-MCL prune -- every row leaves only its kept, normalised entries at the front of its range
   // of dJC/dC and their count in pcnt[row] (rows of bin 8 are written in full and fixed up in place right behind).
-  // pmode 2: no symbolic pass ran, dIC holds the prefix sums of the rows' product counts (bin 8 must be empty)
+  // pmode 2: no symbolic pass ran below bin 8: dIC holds the prefix sums of the rows' product counts there, exact counts
+  // for the rows of bin 8
   const int2* sbl = h->sbl;
   const int* bp = h->dsmall->binPtr;
   int* err = &h->dsmall->err;
@@ -1141,13 +1142,22 @@ extern "C" int hip_rmcl_expand_prune(spgemm_handle* h, const int* dIA, const int
     dIC = cnt = dJC = JN = nullptr; dC = CN = nullptr;
     return two_steps();
   }
-  // No row beyond 4096 products (every R-MCL iteration on a sparse graph): the symbolic pass is SKIPPED.  Its only
-  // product is the exact size of every row of C, and C is not kept: the scratch rows are laid out by the rows' product
-  // counts (known from the classification), every row is hashed in a table sized by its products and the epilogue
-  // counts the distinct columns itself.  Rows of bin 8 pass through LDS in pieces and need the exact counts.
-  const bool nosym = mid.binPtr[NBINS] - mid.binPtr[NBINS - 1] == 0 && !getenv("SPGEMM_RMCL_SYMBOLIC");
+  // The symbolic pass is SKIPPED for every row of at most 4096 products (all rows of an R-MCL iteration on a sparse graph
+  // without hubs).  Its only product is the exact size of every row of C, and C is not kept: the scratch rows are laid
+  // out by the rows' product counts (known from the classification), every such row is hashed in a table sized by its
+  // products and the epilogue counts the distinct columns itself.  Rows of bin 8 pass through LDS in pieces and need
+  // their exact counts: only they get a symbolic kernel (k_sym_big overwrites their entries of dIC).
+  const bool nosym = !getenv("SPGEMM_RMCL_SYMBOLIC");
   if (nosym) {
     if (hipMemcpyAsync(dIC, h->rowFlops, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, s) != hipSuccess) return hipfail("copy");
+    const int nbig = mid.binPtr[NBINS] - mid.binPtr[NBINS - 1];
+    if (nbig > 0) {
+      KTimer t(h, SPGEMM_K_SYM_BIG, s);
+      hipLaunchKernelGGL(k_sym_big, dim3(clampi(nbig, 1, h->numCU)), dim3(BIG_THREADS), sizeof(BigSymShared), s,
+                         h->dsmall->binPtr, 8, h->cur_rowIds, dIA, h->sbl, dJB, n, dIC, h->bigBitmaps, h->bm_cap,
+                         h->dsmall->qctr + 0);
+      if (hipGetLastError() != hipSuccess) return hipfail("symbolic launch");
+    }
   } else if ((rc = launch_symbolic(h, dIA, dJB, m, n, h->cur_rowIds, dIC))) return cleanup(rc);
   hipEventRecord(h->ev[2], s);
   if ((rc = launch_scan(h, dIC, m, &h->dsmall->nnzC64))) return cleanup(rc);

@@ -75,14 +75,20 @@ def _ragged(rows, cols, lens, seed, pools=None):
     return po.CSRHost(rp, ci, v, rows, cols)
 
 
+@pytest.mark.parametrize("sym", [False, True])
 @pytest.mark.parametrize("n,big", [(6000, True), (300000, True), (6000, False), (300000, False)])
-def test_fused_expand_prune_every_kernel(n, big):
+def test_fused_expand_prune_every_kernel(n, big, sym, monkeypatch):
     """hip_rmcl_expand_prune on a rectangular product whose rows land in EVERY bin, with duplicate-free rows (list
     staging) and colliding rows (hash tables) in each: one step against the oracle.
     big: rows beyond 4096 products exist (n = 300000 sends them through the hash kernel and its multi-pass rows,
-    n = 6000 through the rank kernel) -> the operator runs the symbolic pass and fixes those rows up in place;
-    not big: bins 0..7 only -> the operator skips the symbolic pass (rows laid out by product counts)."""
+    n = 6000 through the rank kernel): they alone get a symbolic kernel and are fixed up in place after the numeric one;
+    all other rows are laid out by their product counts, no symbolic pass.  sym: SPGEMM_RMCL_SYMBOLIC forces the
+    variant with the full symbolic pass (exact row pointers, duplicate-free rows staged as plain lists)."""
     import torch
+    if sym:
+        monkeypatch.setenv("SPGEMM_RMCL_SYMBOLIC", "1")
+    else:
+        monkeypatch.delenv("SPGEMM_RMCL_SYMBOLIC", raising=False)
     from sparse_matrix_with_flops_amd.dist import HipEngine, make_matrix
     rng = np.random.default_rng(5)
     m, k = 2500, 4000
@@ -106,7 +112,7 @@ def test_fused_expand_prune_every_kernel(n, big):
     torch.cuda.synchronize()
     st = eng.stats()
     assert all(r > 0 for r in st["bin_rows"][:8]) and (st["bin_rows"][8] > 0) == big, st["bin_rows"]
-    assert (st["nnzC"] == -1) == (not big)                                # -1: no symbolic pass ran
+    assert (st["nnzC"] == -1) == (not sym)                                # -1: nnz of the product not computed
     got = po.CSRHost(rp.cpu().numpy(), ci.cpu().numpy(), v.cpu().numpy(), m, n)
     # rows of more than 512 product entries: the kept sum alone adds thousands of float32 terms in another order than
     # the sequential CPU loop (measured worst 5.6e-6 on rows of ~6000 entries); all other rows at the 3e-6 of the step
