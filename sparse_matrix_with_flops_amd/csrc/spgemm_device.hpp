@@ -1051,7 +1051,7 @@ __device__ __forceinline__ void short_trip(const char* rec, int T, int ns, int r
 // 64*U consecutive products [s0, s0 + 64U) of one long B row: base, length and A value are wave-uniform
 template <int U, bool NEED_VAL, class F>
 __device__ __forceinline__ void long_trip(int kb, int kl, float ka, int s0, const int* __restrict__ JB,
-                                          const float* __restrict__ VB, F&& f) {
+                                          const float* __restrict__ VB, F&& f, int p0row = -1) {
   const int lane = lane_id();
   int col[U];
   float vb[U], val[U];
@@ -1070,7 +1070,7 @@ __device__ __forceinline__ void long_trip(int kb, int kl, float ka, int s0, cons
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int u = 0; u < U; ++u) val[u] = ka * vb[u];
-  f(act, col, val, -1);
+  f(act, col, val, p0row);
 }
 
 // wave-uniform R in 1..8 -> compile-time round count (5 runs as 6, 7 as 8): a trip costs what its rounds cost
@@ -1126,12 +1126,19 @@ for_each_product(WalkStage1& st, int as, int ae, const int2* __restrict__ SBL, c
 }
 
 // ---- NW waves per row
+// num != nullptr: every product gets its index in a dense numbering of the ROW (chunk by chunk: the short products of the
+// chunk's groups first, then its long entries one after the other) and the callback receives the index of the unit's
+// first product -- what the expansion of duplicate-free rows needs to store products without a table.
+template <int NW>
+struct WalkNumber { int lpro[NW][WAVE]; int gLP[NW]; };   // per long entry: products of the group's earlier long entries; their sum
+
 template <int NW, int U, bool NEED_VAL, class F>
 __device__ __forceinline__ typename std::enable_if<(NW > 1)>::type
 for_each_product(WalkStageN<NW>& st, int as, int ae, const int2* __restrict__ SBL, const float* __restrict__ VA,
                  const int* __restrict__ JB, const float* __restrict__ VB, F&& f,
-                 PreA pre = PreA{0, 0, 0.f, false}, int* err = nullptr) {
+                 PreA pre = PreA{0, 0, 0.f, false}, int* err = nullptr, WalkNumber<NW>* num = nullptr) {
   (void)err;
+  int chunkBase = 0;                                     // products of the chunks before this one (numbering only)
   static_assert(NW <= 16, "the unit table of a chunk lives in the first 16 lanes");
   constexpr int K = WAVE * NW;
   constexpr int UP = WAVE * U;                           // products per unit
@@ -1146,6 +1153,11 @@ for_each_product(WalkStageN<NW>& st, int as, int ae, const int2* __restrict__ SB
       const int units = isLong ? (g.len + UP - 1) / UP : 0;
       const int uincl = wave_incl_add(units);
       if (isLong) st.rec[w][WAVE - 1 - mask_rank(g.lmask)] = make_int4(g.bs, __float_as_int(g.a), g.len, uincl - units);
+      if (num) {
+        const int lincl = wave_incl_add(isLong ? g.len : 0);
+        if (isLong) num->lpro[w][mask_rank(g.lmask)] = lincl - g.len;
+        if (lane == 63) num->gLP[w] = lincl;
+      }
       st.wpre[w][lane] = (unsigned char)g.pexcl;
       if (lane == 0) { st.gT[w] = g.T; st.gNS[w] = g.ns; st.gNL[w] = __popcll(g.lmask); }
       if (lane == 63) st.gLU[w] = uincl;
@@ -1161,6 +1173,13 @@ for_each_product(WalkStageN<NW>& st, int as, int ae, const int2* __restrict__ SB
     const int sIncl = wave_incl_add(ntg), lIncl = wave_incl_add(lug);
     const int S = __builtin_amdgcn_readlane(sIncl, 63);
     const int total = S + __builtin_amdgcn_readlane(lIncl, 63);
+    int tIncl = 0, lpIncl = 0, gLPv = 0, shortSum = 0;
+    if (num) {
+      gLPv = lane < NW ? num->gLP[lane] : 0;
+      tIncl = wave_incl_add(gT);
+      lpIncl = wave_incl_add(gLPv);
+      shortSum = __builtin_amdgcn_readlane(tIncl, 63);
+    }
     for (int u = __builtin_amdgcn_readfirstlane(w); u < total;) {
       int unext = 0;
       if (lane == 0) unext = atomicAdd(&st.claim, 1);
@@ -1176,7 +1195,8 @@ for_each_product(WalkStageN<NW>& st, int as, int ae, const int2* __restrict__ SB
           W[uu] = st.marks[g][r];                                          // uniform address: broadcast reads
           base[uu] = st.wpre[g][r];
         }
-        short_trip<U, NEED_VAL, 16>(reinterpret_cast<const char*>(st.rec[g]), T, ns, t * U, W, base, JB, VB, f);
+        const int p0 = num ? chunkBase + (__builtin_amdgcn_readlane(tIncl, g) - T) + t * U * WAVE : -1;
+        short_trip<U, NEED_VAL, 16>(reinterpret_cast<const char*>(st.rec[g]), T, ns, t * U, W, base, JB, VB, f, p0);
       } else {
         const int ul = u - S;
         const int g = __popcll(ballot64(lIncl <= ul));
@@ -1185,13 +1205,17 @@ for_each_product(WalkStageN<NW>& st, int as, int ae, const int2* __restrict__ SB
         const int uex = lane < nl ? st.rec[g][WAVE - 1 - lane].w : 0x7fffffff;   // unit offsets of the group's long entries
         const int k = __popcll(ballot64(uex <= ug)) - 1;
         const int4 r4 = st.rec[g][WAVE - 1 - k];
-        long_trip<U, NEED_VAL>(r4.x, r4.z, __int_as_float(r4.y), (ug - r4.w) * UP, JB, VB, f);
+        const int p0 = num ? chunkBase + shortSum + (__builtin_amdgcn_readlane(lpIncl, g) - __builtin_amdgcn_readlane(gLPv, g)) +
+                                 num->lpro[g][k] + (ug - r4.w) * UP
+                           : -1;
+        long_trip<U, NEED_VAL>(r4.x, r4.z, __int_as_float(r4.y), (ug - r4.w) * UP, JB, VB, f, p0);
       }
       u = __builtin_amdgcn_readfirstlane(unext);
     }
     // the callback's last LDS atomics return nothing (ds_or / ds_add_f32): nothing else waits for them, and a wave
     // that leaves the barrier may read their target before they have landed (seen as lost bitmap bits)
     __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
+    if (num) chunkBase += shortSum + __builtin_amdgcn_readlane(lpIncl, 63);
     __syncthreads();
   }
 }
@@ -1334,7 +1358,8 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
   }
   const int* rows = rowIds + first;
   int q = NW > 1 ? next_row<QB>(qctr, &qslot, -1) : (int)(blockIdx.x >> 3);
-  const int* const rf = NW == 1 ? rowFlops : nullptr;    // wave-per-row: the product count decides hash vs expansion
+  const int* const rf = rowFlops;                        // the product count decides hash vs expansion
+  __shared__ WalkNumber<(NW > 1 ? NW : 2)> wnum;         // (several waves per row: product numbering of expanded rows)
   RowMeta cur = load_meta_num(rows, q, count, IA, IC, rf);
   RowMeta nxt = NW == 1 ? load_meta_num(rows, q + stride, count, IA, IC, rf) : RowMeta{0, 0, 0, 0, 0, 0};
   PreA pc = NW == 1 ? load_pre(cur, SBL, VA, true) : PreA{0, 0, 0.f, false};
@@ -1348,7 +1373,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
       pn = load_pre(nxt, SBL, VA, true);
     } else {
       qn = next_row<QB>(qctr, &qslot, q);
-      nxt = load_meta_num(rows, qn, count, IA, IC);
+      nxt = load_meta_num(rows, qn, count, IA, IC, rf);
     }
     const int off = cur.x0;
     const int want = cur.x1 - off;                      // exact distinct count from the symbolic pass
@@ -1391,6 +1416,24 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
       }, pc, err);
       cur = nxt;
       if (NW == 1) { nxt = nn; pc = pn; }
+      q = qn;
+      continue;
+    }
+    if constexpr (NW > 1 && PRUNE == 0) if (want == cur.x2) {
+      // several waves per row, no repeated column (77 % of the rows of 513-1024 products on a power-law matrix): expanded
+      // like the wave-per-row case, positions from the walk's dense product numbering
+      int* const JCrow = JC + off;
+      float* const Crow = C + off;
+      for_each_product<NW, U, true>(st, cur.as, cur.ae, SBL, VA, JB, VB,
+                                    [&](const auto& act, const auto& col, const auto& val, int p0) {
+        constexpr int R = (int)(sizeof(col) / sizeof(col[0]));
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          const unsigned o = (unsigned)(p0 + u * WAVE + lane_id());
+          if (act[u] && o < (unsigned)want) { st_out(JCrow + o, col[u]); st_out(Crow + o, val[u]); }
+        }
+      }, pc, err, reinterpret_cast<WalkNumber<NW>*>(&wnum));
+      cur = nxt;
       q = qn;
       continue;
     }
