@@ -218,3 +218,41 @@ def test_cpp_mirror_runs_the_reference_test_protocol():
         assert "rmclOption= GPU" in out.stdout and "Same" in out.stdout and "Diffs" not in out.stdout
         if "--stats" in args:
             assert "Total sum =" in out.stdout
+
+
+def test_fused_expand_prune_degenerate_shapes():
+    """hip_rmcl_expand_prune on products with nothing in them: no rows, rows without products (B empty, A empty) and a
+    single 1x1 product -- the paths that bypass the fused kernels."""
+    import torch
+    from sparse_matrix_with_flops_amd.dist import HipEngine, make_matrix
+    eng = HipEngine(0)
+
+    def mk(rp, ci, v, r, c):
+        return make_matrix(eng, np.asarray(rp, np.int32), np.asarray(ci, np.int32), np.asarray(v, np.float32), r, c)
+
+    # A 3x4 with entries, B 4x5 empty: every row of the product is empty
+    A = mk([0, 2, 2, 3], [0, 3, 1], [1.0, 2.0, 3.0], 3, 4)
+    B = mk([0, 0, 0, 0, 0], [], [], 4, 5)
+    rp, ci, v = eng.expand_prune(A, B)
+    torch.cuda.synchronize()
+    assert rp.cpu().tolist() == [0, 0, 0, 0] and ci.numel() == 0
+    # A empty
+    A0 = mk([0, 0, 0, 0], [], [], 3, 4)
+    B1 = mk([0, 1, 2, 2, 3], [0, 4, 2], [1.0, 1.0, 1.0], 4, 5)
+    rp, ci, v = eng.expand_prune(A0, B1)
+    torch.cuda.synchronize()
+    assert rp.cpu().tolist() == [0, 0, 0, 0] and ci.numel() == 0
+    # 1x1
+    A1 = mk([0, 1], [0], [0.5], 1, 1)
+    rp, ci, v = eng.expand_prune(A1, A1)
+    torch.cuda.synchronize()
+    assert rp.cpu().tolist() == [0, 1] and ci.cpu().tolist() == [0] and abs(float(v.cpu()[0]) - 1.0) < 1e-6
+    # one row keeps exactly what the rule says: values (3, 1, 1) -> squares 9, 1, 1: avg 11/3, max 9 > avg -> th clamps low
+    A2 = mk([0, 3], [0, 1, 2], [3.0, 1.0, 1.0], 1, 3)
+    I3 = mk([0, 1, 2, 3], [0, 1, 2], [1.0, 1.0, 1.0], 3, 3)
+    rp, ci, v = eng.expand_prune(A2, I3)
+    torch.cuda.synchronize()
+    got = po.CSRHost(rp.cpu().numpy(), ci.cpu().numpy(), v.cpu().numpy(), 1, 3)
+    Ah = po.CSRHost(np.array([0, 3], np.int32), np.array([0, 1, 2], np.int32), np.array([3, 1, 1], np.float32), 1, 3)
+    Ih = po.CSRHost(np.array([0, 1, 2, 3], np.int32), np.array([0, 1, 2], np.int32), np.ones(3, np.float32), 3, 3)
+    assert_rmcl_step(got, Ah, Ih, what="1x3 row")
