@@ -1131,6 +1131,7 @@ for_each_product(WalkStage1& st, int as, int ae, const int2* __restrict__ SBL, c
 // first product -- what the expansion of duplicate-free rows needs to store products without a table.
 template <int NW>
 struct WalkNumber { int lpro[NW][WAVE]; int gLP[NW]; };   // per long entry: products of the group's earlier long entries; their sum
+static_assert(sizeof(WalkNumber<8>) <= 4096 * sizeof(unsigned long long), "lives in the (idle) hash table of an expanded row");
 
 template <int NW, int U, bool NEED_VAL, class F>
 __device__ __forceinline__ typename std::enable_if<(NW > 1)>::type
@@ -1359,7 +1360,6 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
   const int* rows = rowIds + first;
   int q = NW > 1 ? next_row<QB>(qctr, &qslot, -1) : (int)(blockIdx.x >> 3);
   const int* const rf = rowFlops;                        // the product count decides hash vs expansion
-  __shared__ WalkNumber<(NW > 1 ? NW : 2)> wnum;         // (several waves per row: product numbering of expanded rows)
   RowMeta cur = load_meta_num(rows, q, count, IA, IC, rf);
   RowMeta nxt = NW == 1 ? load_meta_num(rows, q + stride, count, IA, IC, rf) : RowMeta{0, 0, 0, 0, 0, 0};
   PreA pc = NW == 1 ? load_pre(cur, SBL, VA, true) : PreA{0, 0, 0.f, false};
@@ -1432,7 +1432,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
           const unsigned o = (unsigned)(p0 + u * WAVE + lane_id());
           if (act[u] && o < (unsigned)want) { st_out(JCrow + o, col[u]); st_out(Crow + o, val[u]); }
         }
-      }, pc, err, reinterpret_cast<WalkNumber<NW>*>(&wnum));
+      }, pc, err, reinterpret_cast<WalkNumber<NW>*>(tab));   // the table is idle in an expanded row: its memory holds the numbering
       cur = nxt;
       q = qn;
       continue;

@@ -142,7 +142,11 @@ struct HostMirror {                 // one small device block + its pinned host 
   int binPtr[NBINS + 1];
   int err;
   int scratch2[4];                  // counts of the 513-2048 / 2049-4096 / 65-256 / 513-1024 rows when a classification is unpacked
-  int qctr[8];                      // work-queue heads of the block-per-row kernels (zeroed with the rest per call)
+  // work-queue heads of the block-per-row kernels (zeroed with the rest per call).  One 128-byte line EACH: the kernels
+  // of a phase run side by side and every dequeue is an atomic on its word -- eight words in one line (next to binPtr /
+  // slotBase, which every block reads when it starts) made all of them queue up behind one another in the L2.
+  alignas(128) int qctr[8 * 32];
+  alignas(128) int qpad_;
   int slotBase[NSLOTS + 1];         // first position of every layout slot in rowIds, [NSLOTS] = m (k_bin_scan)
   unsigned long long totalP;
   unsigned long long nnzC64;
@@ -467,20 +471,20 @@ static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJB,
   fork_streams(h);
   { hipStream_t st = h->side[3]; KTimer t(h, SPGEMM_K_SYM_BIG, st);
     hipLaunchKernelGGL(k_sym_big, dim3(clampi(m, 1, cu)), dim3(BIG_THREADS), sizeof(BigSymShared), st, bp, 8,
-                       rowIds, dIA, sbl, dJB, n, dIC, h->bigBitmaps, h->bm_cap, qc + 0); }
+                       rowIds, dIA, sbl, dJB, n, dIC, h->bigBitmaps, h->bm_cap, qc + 0 * 32); }
   { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_SYM_HASH8, st);
     LAUNCH_U(k_sym_hash, 8, 8192, dim3(clampi(m, 1, cu * 3)), dim3(512), st, bp, 7, rowIds, dIA,
-             sbl, dJB, h->rowFlops, dIC, err, qc + 1); }
+             sbl, dJB, h->rowFlops, dIC, err, qc + 1 * 32); }
   { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_SYM_HASH4, st);
     // (one launch for both layout slots of bin 6: split like the numeric side it measured 15 % slower)
     LAUNCH_U(k_sym_hash, 4, 4096, dim3(clampi(m, 1, cu * 8)), dim3(256), st, bp, 6, rowIds, dIA,
-             sbl, dJB, h->rowFlops, dIC, err, qc + 2); }
+             sbl, dJB, h->rowFlops, dIC, err, qc + 2 * 32); }
   { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_SYM_HASH1, st);
     const int* sb = h->dsmall->slotBase;         // bin 5 = two layout slots: table 512 up to 256 products, 1024 above
     LAUNCH_U(k_sym_hash, 1, 512, dim3(grid8(m, cu * h->h1sym)), dim3(64), st, sb, SLOT_H1A, rowIds, dIA,
-             sbl, dJB, h->rowFlops, dIC, err, qc + 3);
+             sbl, dJB, h->rowFlops, dIC, err, qc + 3 * 32);
     LAUNCH_U(k_sym_hash, 1, 1024, dim3(grid8(m, cu * h->h1sym)), dim3(64), st, sb, SLOT_H1B, rowIds, dIA,
-             sbl, dJB, h->rowFlops, dIC, err, qc + 3); }
+             sbl, dJB, h->rowFlops, dIC, err, qc + 3 * 32); }
   { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_SYM_G16, st);
     hipLaunchKernelGGL((k_sym_g16<128, 4>), dim3(grid8(cdiv(m, 16), cu * 16)), dim3(256), 0, st, bp, 4, 5,
                        rowIds, dIA, sbl, dJB, h->rowFlops, dIC, err); }
@@ -522,7 +526,7 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
     if (n <= BIG_WC) { KTimer t(h, SPGEMM_K_NUM_BIG, st);
       hipLaunchKernelGGL(k_num_big, dim3(clampi(rows(8, 9), 1, cu)), dim3(BIG_THREADS), sizeof(BigNumShared), st,
                          bp, 8, rowIds, dIA, sbl, dA, dJB, dB, n, dIC, dJC, dC, err, h->bigBitmaps, h->bm_cap,
-                         qc + 4);
+                         qc + 4 * 32);
     } else { KTimer t(h, SPGEMM_K_NUM_BIGHASH, st);
       const int blocks = clampi(rows(8, 9), 1, cu);
       if (blocks > h->spill_blocks) {                  // parking space of multi-pass rows: 1 MB per block, kept
@@ -533,30 +537,30 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
         else (void)hipGetLastError();                  // without it those rows walk once per pass
       }
       hipLaunchKernelGGL(k_num_bighash, dim3(blocks), dim3(BIG_THREADS), sizeof(BigHashShared), st,
-                         bp, 8, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 4, h->rowFlops,
+                         bp, 8, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 4 * 32, h->rowFlops,
                          h->spill_blocks >= blocks ? h->spill : (int2*)nullptr, BH_SPILL, h->bhCap, h->bhMargin); }
     if (pcnt) hipLaunchKernelGGL(k_rmcl_fix_rows, dim3(clampi(rows(8, 9), 1, cu * 8)), dim3(256), 0, st,
                                  bp, 8, 9, rowIds, dIC, dJC, dC, pcnt);
   }
   if (rows(7, 8) > 0) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_NUM_HASH8, st);
     LAUNCH_NUM(8, 8192, dim3(clampi(rows(7, 8), 1, cu * 2)), dim3(512), st, bp, 7,
-             rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 5, h->rowFlops); }
+             rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 5 * 32, h->rowFlops); }
   if (rows(6, 7) > 0) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_NUM_HASH4, st);
     const int* sb = h->dsmall->slotBase;
     const int* hs_ = h->mirror.slotBase;
     const int na = hs_[SLOT_H4A + 1] - hs_[SLOT_H4A], nb = hs_[SLOT_H4B + 1] - hs_[SLOT_H4B];
     if (na > 0) LAUNCH_NUM(4, 2048, dim3(clampi(na, 1, cu * 7)), dim3(256), st, sb, SLOT_H4A,
-                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 6, h->rowFlops);
+                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 6 * 32, h->rowFlops);
     if (nb > 0) LAUNCH_NUM(4, 4096, dim3(clampi(nb, 1, cu * 4)), dim3(256), st, sb, SLOT_H4B,
-                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7, h->rowFlops); }
+                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7 * 32, h->rowFlops); }
   if (rows(5, 6) > 0) { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_NUM_HASH1, st);
     const int* sb = h->dsmall->slotBase;
     const int* hs_ = h->mirror.slotBase;
     const int na = hs_[SLOT_H1A + 1] - hs_[SLOT_H1A], nb = hs_[SLOT_H1B + 1] - hs_[SLOT_H1B];
     if (na > 0) LAUNCH_NUM(1, 512, dim3(grid8(na, cu * 24)), dim3(64), st, sb, SLOT_H1A,
-                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7, h->rowFlops);
+                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7 * 32, h->rowFlops);
     if (nb > 0) LAUNCH_NUM(1, 1024, dim3(grid8(nb, cu * 16)), dim3(64), st, sb, SLOT_H1B,
-                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7, h->rowFlops); }
+                         rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7 * 32, h->rowFlops); }
   if (rows(4, 5) > 0) { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_NUM_G16, st);
     if (pcnt && pmode == 2) hipLaunchKernelGGL((k_num_g16<128, 4, 2>), dim3(grid8(cdiv(rows(4, 5), 16), cu * 16)), dim3(256), 0, st,
                                                bp, 4, 5, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, h->rowFlops, pcnt);
@@ -1155,7 +1159,7 @@ extern "C" int hip_rmcl_expand_prune(spgemm_handle* h, const int* dIA, const int
       KTimer t(h, SPGEMM_K_SYM_BIG, s);
       hipLaunchKernelGGL(k_sym_big, dim3(clampi(nbig, 1, h->numCU)), dim3(BIG_THREADS), sizeof(BigSymShared), s,
                          h->dsmall->binPtr, 8, h->cur_rowIds, dIA, h->sbl, dJB, n, dIC, h->bigBitmaps, h->bm_cap,
-                         h->dsmall->qctr + 0);
+                         h->dsmall->qctr + 0 * 32);
       if (hipGetLastError() != hipSuccess) return hipfail("symbolic launch");
     }
   } else if ((rc = launch_symbolic(h, dIA, dJB, m, n, h->cur_rowIds, dIC))) return cleanup(rc);
