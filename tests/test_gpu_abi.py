@@ -120,3 +120,35 @@ def test_classification_scan_is_consistent_beyond_2_pow_31_products():
     assert np.array_equal(per, lens[rowIds]), (per, lens[rowIds])     # every row, the last one included
     for p in (dIA, dJA, dIB, ids.value, fl.value):
         hs.dev_free(p)
+
+
+def test_more_than_2_pow_30_products_take_the_two_phase_path():
+    """hip_gpuSpMM sizes C by P only up to 2^30 products; beyond that it finishes the symbolic phase first and
+    allocates exactly nnz(C).  65 536 rows x 130 entries x B rows of 128 entries = 1.09e9 products onto 128 columns
+    (values chosen so that every float sum is exact).  The fused R-MCL step falls back to SpGEMM + prune there."""
+    import torch
+    from sparse_matrix_with_flops_amd.dist import HipEngine, make_matrix
+    m, alen, k, blen = 1 << 16, 130, 512, 128
+    rng = np.random.default_rng(3)
+    rpA = (np.arange(m + 1, dtype=np.int64) * alen).astype(np.int32)
+    ciA = np.tile(np.arange(alen, dtype=np.int32), m) + np.repeat(rng.integers(0, k - alen, size=m).astype(np.int32), alen)
+    vA = rng.integers(1, 3, size=m * alen).astype(np.float32)
+    rpB = (np.arange(k + 1, dtype=np.int64) * blen).astype(np.int32)
+    ciB = np.tile(np.arange(blen, dtype=np.int32), k)
+    vB = np.ones(k * blen, dtype=np.float32)
+    eng = HipEngine(0)
+    A = make_matrix(eng, rpA, ciA, vA, m, k)
+    B = make_matrix(eng, rpB, ciB, vB, k, blen)
+    C_ = eng.spmm(A, B)
+    st = eng.stats()
+    assert st["total_flops"] == m * alen * blen > (1 << 30)
+    rp, ci, v = C_.to_host()
+    C_.release()
+    assert np.array_equal(rp, np.arange(m + 1, dtype=np.int64) * blen)
+    assert np.array_equal(np.sort(ci.reshape(m, blen), axis=1), np.tile(np.arange(blen, dtype=np.int32), (m, 1)))
+    want = vA.reshape(m, alen).sum(axis=1)
+    assert np.array_equal(v.reshape(m, blen), np.repeat(want[:, None], blen, axis=1))
+    prp, pci, pv = eng.expand_prune(A, B)
+    torch.cuda.synchronize()
+    assert np.array_equal(prp.cpu().numpy(), rp) and pci.numel() == m * blen      # equal values: everything is kept
+    assert np.allclose(pv.cpu().numpy(), 1.0 / blen, rtol=1e-6)
