@@ -152,3 +152,27 @@ def test_more_than_2_pow_30_products_take_the_two_phase_path():
     torch.cuda.synchronize()
     assert np.array_equal(prp.cpu().numpy(), rp) and pci.numel() == m * blen      # equal values: everything is kept
     assert np.allclose(pv.cpu().numpy(), 1.0 / blen, rtol=1e-6)
+
+
+def test_nnzC_beyond_int32_is_refused():
+    """131 072 rows x 129 entries x B rows of 128 entries with disjoint columns: nnz(C) = P = 2.16e9 > 2^31 - 1.  The
+    symbolic phase counts it (64-bit total) and the call fails with SPGEMM_ERR_OVERFLOW instead of wrapping."""
+    from sparse_matrix_with_flops_amd.dist import HipEngine, make_matrix
+    m, alen, k, blen = 1 << 17, 129, 4096, 128
+    rng = np.random.default_rng(4)
+    rpA = (np.arange(m + 1, dtype=np.int64) * alen).astype(np.int32)
+    ciA = np.tile(np.arange(alen, dtype=np.int32), m) + np.repeat(rng.integers(0, k - alen, size=m).astype(np.int32), alen)
+    vA = np.ones(m * alen, dtype=np.float32)
+    rpB = (np.arange(k + 1, dtype=np.int64) * blen).astype(np.int32)
+    ciB = np.arange(k * blen, dtype=np.int32)                       # row j owns columns [128 j, 128 j + 128)
+    vB = np.ones(k * blen, dtype=np.float32)
+    eng = HipEngine(0)
+    A = make_matrix(eng, rpA, ciA, vA, m, k)
+    B = make_matrix(eng, rpB, ciB, vB, k, k * blen)
+    with pytest.raises(Exception) as ei:
+        eng.spmm(A, B)
+    assert "does not fit int32" in str(ei.value)
+    # the handle is usable afterwards
+    small = synth_csr(4096, 11, 2)
+    got = hs.gpuSpMMWrapper(to_hs(small).toGpuCSR(), to_hs(small).toGpuCSR(), eng.handle).toCpuCSR()
+    assert got.nnz == po.omp_spmm(small, small).nnz
