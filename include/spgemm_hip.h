@@ -41,7 +41,7 @@ typedef struct spgemm_handle spgemm_handle;
 /* per-call statistics (filled by every SpGEMM entry point that takes a handle) */
 typedef struct spgemm_stats {
   long long total_flops;          /* P = sum over A nonzeros of nnz(B row): "intermediate_nnz"           */
-  int       nnzC;
+  int       nnzC;                 /* nnz of the product; -1 after hip_rmcl_expand_prune (the product is never counted) */
   int       bin_rows[SPGEMM_NBINS];/* rows per internal bin {0 | 1 | 2-4 | 5-16 | 17-64 | 65-512 | 513-2048 | 2049-4096 | >4096} */
   float     ms_classify;          /* HIP-event times on the handle's stream                              */
   float     ms_symbolic;
