@@ -209,6 +209,20 @@ void gpuRmclIter(const int maxIter, const CSR Mgt, CSR& Mt) {
   Mt.init(oA, oJ, oI, Mgt.rows, Mgt.cols, on);
 }
 
+void gpuOutputCSRWrapper(const CSR dA, const char* msg) {
+  printf("%s\n", msg);
+  printf("rows=%d cols=%d nnz=%d rowPtr=%p colInd=%p values=%p\n", dA.rows, dA.cols, dA.nnz, (void*)dA.rowPtr,
+         (void*)dA.colInd, (void*)dA.values);
+  CSR h = dA.toCpuCSR();
+  for (int r = 0; r < h.rows; ++r)
+    for (int p = h.rowPtr[r]; p < h.rowPtr[r + 1]; ++p) printf("%d\t%d\t%.6lf\n", r, h.colInd[p], (double)h.values[p]);
+  printf("rowPtr= ");
+  for (int r = 0; r <= h.rows; ++r) printf("%d ", h.rowPtr[r]);
+  printf("\ncolInd, values= ");
+  for (int p = 0; p < h.nnz; ++p) printf("%d:%.6lf ", h.colInd[p], (double)h.values[p]);
+  printf("\n");
+  h.dispose();
+}
 
 std::vector<int> CSR::nnzStats() const {
   std::vector<int> stats(SPGEMM_NNZ_STATS_LEN, 0);

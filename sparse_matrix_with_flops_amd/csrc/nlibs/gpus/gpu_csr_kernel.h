@@ -15,6 +15,9 @@ std::vector<int> gpuFlopsClassify(const CSR& dA, const CSR& dB, int** drowIdsp, 
 CSR sgpuSpMMWrapper(const CSR& dA, const CSR& dB, int* drowIds, const std::vector<int>& hv, int* dflops);
 CSR scudaSpMM(const CSR& hA, const CSR& hB);
 void gpuRmclIter(const int maxIter, const CSR Mgt, CSR& Mt);
+// debug dump of a DEVICE CSR (nlibs/gpus/gpu_csr_kernel.h:7, .cu:15-42: message, shape and device pointers, the triples,
+// then the raw rowPtr and colInd/values arrays); the arrays are brought to the host and printed there
+void gpuOutputCSRWrapper(const CSR dA, const char* msg);
 
 // bool resultsComparison(CSR& hC, CSR& rC, const vector<int>& hv, const int* hqueue) (mindex2-cuda/nGpuSpMM.cc:138-240):
 // hC (result under test) against rC (reference result), whole matrix first, then bin by bin; prints one line per bin

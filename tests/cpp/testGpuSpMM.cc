@@ -67,6 +67,7 @@ int main(int argc, char* argv[]) {
   outputStats(gpuFlopsStats(dA, dB));            // tools/stats.cc report: rows by power-of-two flop class
   outputStats(dA.gpuNnzStats());                 // CSR::nnzStats of the input: rows by power-of-two length class
   CSR dC = gpuSpMMWrapper(dA, dB);
+  if (A.rows <= 8) gpuOutputCSRWrapper(dC, "C = A*A on the device (gpuOutputCSRWrapper)");   // tiny inputs only
   CSR hC = dC.toCpuCSR();
   dC.deviceDispose();
   {                                               // per-bin report, like resultsComparison (nGpuSpMM.cc:138-240)
