@@ -256,3 +256,24 @@ def test_fused_expand_prune_degenerate_shapes():
     Ah = po.CSRHost(np.array([0, 3], np.int32), np.array([0, 1, 2], np.int32), np.array([3, 1, 1], np.float32), 1, 3)
     Ih = po.CSRHost(np.array([0, 1, 2, 3], np.int32), np.array([0, 1, 2], np.int32), np.ones(3, np.float32), 3, 3)
     assert_rmcl_step(got, Ah, Ih, what="1x3 row")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_fused_expand_prune_random_rectangular(seed):
+    """Random rectangular A (m x k) and B (k x n) with unsorted rows and non-negative values (what R-MCL multiplies;
+    with mixed signs a product can be the small difference of large terms and no summation order is within a relative
+    bound of another -- the SpGEMM parity rule of DESIGN.md section 2): the fused step against the oracle step."""
+    import torch
+    from helpers import random_csr
+    from sparse_matrix_with_flops_amd.dist import HipEngine, make_matrix
+    rng = np.random.default_rng(seed)
+    m, k, n = int(rng.integers(50, 400)), int(rng.integers(50, 400)), int(rng.integers(50, 3000))
+    A = random_csr(m, k, float(rng.uniform(0.01, 0.2)), 100 + seed, sorted_rows=False, signed=False)
+    B = random_csr(k, n, float(rng.uniform(0.01, 0.2)), 200 + seed, sorted_rows=False, signed=False)
+    eng = HipEngine(0)
+    dA = make_matrix(eng, A.rowPtr, A.colInd, A.values, A.rows, A.cols)
+    dB = make_matrix(eng, B.rowPtr, B.colInd, B.values, B.rows, B.cols)
+    rp, ci, v = eng.expand_prune(dA, dB)
+    torch.cuda.synchronize()
+    got = po.CSRHost(rp.cpu().numpy(), ci.cpu().numpy(), v.cpu().numpy(), m, n)
+    assert_rmcl_step(got, A, B, what=f"seed {seed}", rel_long=(512, 2e-5))
