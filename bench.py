@@ -16,6 +16,7 @@ Workloads (SURVEY.md §8d generator, sparse_matrix_with_flops_amd/synth.py):
   synth_1m_16    1 048 576^2, ~16 nnz/row, seed 43   <- default: the configuration the metric is quoted on
   synth_256k_16  262 144^2,  ~16 nnz/row, seed 42    (BASELINE.json configs[1])
   synth_1m_32    1 048 576^2, ~32 nnz/row, seed 44   (configs[3], the row-sharded multi-GPU case)
+  web_google_surrogate  916 428^2, ~5.5 nnz/row, nnzC/P ~0.49 (configs[2] by shape; the real file is not available)
 """
 import argparse
 import json
@@ -34,6 +35,10 @@ WORKLOADS = {
     "synth_256k_16": dict(m=1 << 18, seed=42, base=2, desc="synthetic power-law CSR 262144^2, ~16 nnz/row, seed 42, C=A*A"),
     "synth_1m_32": dict(m=1 << 20, seed=44, base=4, desc="synthetic power-law CSR 1048576^2, ~32 nnz/row, seed 44, C=A*A"),
     "synth_64k_16": dict(m=1 << 16, seed=17, base=2, desc="synthetic power-law CSR 65536^2 (smoke-sized)"),
+    # BASELINE.json configs[2] by shape (the real file is in neither container): synth.webgraph_csr, nnzC/P = 0.49
+    "web_google_surrogate": dict(m=916428, seed=46, gen="web",
+                                 desc="web-Google-shaped surrogate 916428^2, ~5.5 nnz/row, nnzC/P~0.49, seed 46, C=A*A "
+                                      "(surrogate; reference totals unpinned)"),
 }
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -142,7 +147,10 @@ def main():
 
     wl = WORKLOADS[args.workload]
     t0 = time.time()
-    rp, ci, v = synth.powerlaw_csr(wl["m"], wl["seed"], wl["base"])
+    if wl.get("gen") == "web":
+        rp, ci, v = synth.webgraph_csr(wl["m"], wl["seed"])
+    else:
+        rp, ci, v = synth.powerlaw_csr(wl["m"], wl["seed"], wl["base"])
     m = wl["m"]
     gen_s = time.time() - t0
     chunks = max(1, args.chunks) if world > 1 else 1
