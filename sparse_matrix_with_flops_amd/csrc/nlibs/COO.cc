@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <cctype>
+#include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,55 +33,179 @@ void COO::dispose() {
   free(cooVal); cooVal = 0;
 }
 
+// ---- text -> triplets -----------------------------------------------------------------------------------------------
+// The reference parses one fgets/sscanf line at a time on one thread (nlibs/COO.cc:130-155); for a 1 M-row edge list
+// that is the longest step of the whole run.  Here the file is read into memory once and the
+// edge lines are parsed by all host threads: the data region is cut at line ends into one chunk per thread, a first
+// sweep counts the lines of every chunk (so that line k of the file lands in slot k of the arrays whatever thread
+// parses it), a second sweep converts them with strtol/strtof -- the conversions sscanf("%d%d%f") performs.  Kept from
+// the reference: at most `declared` entries are read, reading stops at the first line that does not start with two
+// integers, a missing third field means 1.0, MatrixMarket indices are 1-based, isTrans swaps the two.  Symmetric
+// MatrixMarket files are a token stream in the reference (fscanf, not lines) and stay on the sequential path.
+// (One deliberate difference: fgets cuts lines at 1024 characters; here a line ends at its newline.)
+namespace {
+struct LineCursor {                         // fgets over a memory buffer
+  const char* p; const char* end;
+  bool next(std::string& out) {
+    if (p >= end) return false;
+    const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+    const char* stop = nl ? nl + 1 : end;
+    out.assign(p, stop);
+    p = stop;
+    return true;
+  }
+};
+
+// parse "from to [val]" from the NUL-terminated line s; returns the number of fields sscanf("%d%d%f") would convert
+inline int parse_edge(const char* s, int* from, int* to, float* val) {
+  char* e = nullptr;
+  const long a = strtol(s, &e, 10);
+  if (e == s) return 0;
+  const char* s2 = e;
+  const long b = strtol(s2, &e, 10);
+  if (e == s2) return 1;
+  *from = (int)a; *to = (int)b;
+  const char* s3 = e;
+  const float v = strtof(s3, &e);
+  if (e == s3) return 2;
+  *val = v;
+  return 3;
+}
+
+size_t count_lines(const char* b, const char* e) {
+  size_t n = 0;
+  while (b < e) {
+    const char* nl = (const char*)memchr(b, '\n', (size_t)(e - b));
+    ++n;
+    if (!nl) break;
+    b = nl + 1;
+  }
+  return n;
+}
+}  // namespace
+
+double COO::lastParseMs = 0.0;
+int COO::lastParseThreads = 0;
+
 int COO::readSNAPFile(const char fname[], bool isTrans) {
-  FILE* fp = fopen(fname, "r");
+  const auto t0 = std::chrono::steady_clock::now();
+  FILE* fp = fopen(fname, "rb");
   if (!fp) { printf("Failed to open file %s\n", fname); exit(-1); }
-  char line[1025];
-  bool isMtx = false, symmetric = false;
+  fseek(fp, 0, SEEK_END);
+  const long fsize = ftell(fp);
+  fseek(fp, 0, SEEK_SET);
+  char* buf = grab<char>((size_t)std::max(fsize, 0l) + 1, "file buffer");
+  const size_t len = fsize > 0 ? fread(buf, 1, (size_t)fsize, fp) : 0;
+  fclose(fp);
+  buf[len] = '\0';
   rows = cols = nnz = 0;
-  if (!fgets(line, sizeof line, fp)) { fclose(fp); return 0; }
+  LineCursor cur{buf, buf + len};
+  std::string line;
+  bool isMtx = false, symmetric = false;
+  if (!cur.next(line)) { free(buf); return 0; }
   if (line[0] == '%') {                      // MatrixMarket banner: 5 tokens, the 5th is the storage scheme
     char t[5][64];
-    if (sscanf(line, "%63s %63s %63s %63s %63s", t[0], t[1], t[2], t[3], t[4]) == 5) {
+    if (sscanf(line.c_str(), "%63s %63s %63s %63s %63s", t[0], t[1], t[2], t[3], t[4]) == 5) {
       isMtx = true;
       symmetric = lower(t[4]) == "symmetric";
     }
   }
-  while ((line[0] == '#' || line[0] == '%') && !feof(fp))
-    if (!fgets(line, sizeof line, fp)) break;
-  if (feof(fp)) { fclose(fp); nnz = 0; return 0; }
+  bool more = true;
+  while (line[0] == '#' || line[0] == '%') { more = cur.next(line); if (!more) break; }
+  if (!more) { free(buf); nnz = 0; return 0; }
   int a = 0, b = 0, c = 0;
-  const int got = sscanf(line, "%d %d %d", &a, &b, &c);
+  const int got = sscanf(line.c_str(), "%d %d %d", &a, &b, &c);
   int declared;
   if (got == 2) { rows = cols = a; declared = b; }
   else if (got == 3) { rows = a; cols = b; declared = c; }
   else { printf("%s: cannot parse the size line\n", fname); exit(-1); }
   printf("rows=%d cols=%d nnz=%d\n", rows, cols, declared);
+  if (declared < 0) declared = 0;
   const size_t cap = (size_t)declared * (symmetric ? 2 : 1);
   cooRowIndex = grab<int>(cap, "cooRowIndex");
   cooColIndex = grab<int>(cap, "cooColIndex");
   cooVal = grab<QValue>(cap, "cooVal");
   int top = 0;
-  for (int i = 0; i < declared; ++i) {
-    int from = 0, to = 0;
-    float val = 0.f;
-    int ret;
-    if (symmetric) ret = fscanf(fp, "%d%d%f", &from, &to, &val);
-    else { if (!fgets(line, sizeof line, fp)) break; ret = sscanf(line, "%d%d%f", &from, &to, &val); }
-    if (ret < 2) break;
-    if (ret == 2) val = 1.0f;
-    if (isMtx) { --from; --to; }
-    if (symmetric) {
+  lastParseThreads = 1;
+  if (symmetric) {                           // token stream (the reference uses fscanf here): sequential
+    const char* p = cur.p;
+    for (int i = 0; i < declared; ++i) {
+      int from = 0, to = 0;
+      float val = 0.f;
+      char* e = nullptr;
+      const long x = strtol(p, &e, 10);
+      if (e == p) break;
+      p = e;
+      const long y = strtol(p, &e, 10);
+      if (e == p) break;
+      p = e;
+      from = (int)x; to = (int)y;
+      const float v = strtof(p, &e);
+      if (e == p) val = 1.0f; else { val = v; p = e; }
+      if (isMtx) { --from; --to; }
       cooRowIndex[top] = from; cooColIndex[top] = to; cooVal[top++] = val;
       if (from != to) { cooRowIndex[top] = to; cooColIndex[top] = from; cooVal[top++] = val; }
-    } else {
-      cooRowIndex[top] = isTrans ? to : from;
-      cooColIndex[top] = isTrans ? from : to;
-      cooVal[top++] = val;
     }
+  } else {
+    char* const d0 = buf + (cur.p - buf);
+    char* const d1 = buf + len;
+    const size_t bytes = (size_t)(d1 - d0);
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char* e = getenv("SMF_PARSE_THREADS")) hw = (unsigned)std::max(1, atoi(e));
+    const int T = (int)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(hw ? hw : 1, 64), bytes / (1 << 16) + 1));
+    lastParseThreads = T;
+    std::vector<char*> cut((size_t)T + 1);
+    cut[0] = d0; cut[T] = d1;
+    for (int t = 1; t < T; ++t) {            // chunk t starts right behind a newline
+      char* p = d0 + bytes * (size_t)t / (size_t)T;
+      if (p < cut[t - 1]) p = cut[t - 1];
+      char* nl = (char*)memchr(p, '\n', (size_t)(d1 - p));
+      cut[t] = nl ? nl + 1 : d1;
+    }
+    std::vector<size_t> nlines((size_t)T), first((size_t)T + 1);
+    std::vector<long long> badAt((size_t)T, -1);   // file-order index of the chunk's first line that is not an edge
+    {
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; ++t) th.emplace_back([&, t] { nlines[t] = count_lines(cut[t], cut[t + 1]); });
+      for (auto& x : th) x.join();
+    }
+    first[0] = 0;
+    for (int t = 0; t < T; ++t) first[t + 1] = first[t] + nlines[t];
+    {
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+        char* p = cut[t];
+        char* const e = cut[t + 1];
+        size_t k = first[t];
+        while (p < e && k < (size_t)declared) {
+          char* nl = (char*)memchr(p, '\n', (size_t)(e - p));
+          char* stop = nl ? nl : e;           // (e == d1 points at the buffer's terminating NUL)
+          const char saved = *stop;
+          *stop = '\0';
+          int from = 0, to = 0;
+          float val = 0.f;
+          const int ret = parse_edge(p, &from, &to, &val);
+          *stop = saved;
+          if (ret < 2) { badAt[t] = (long long)k; return; }
+          if (ret == 2) val = 1.0f;
+          if (isMtx) { --from; --to; }
+          cooRowIndex[k] = isTrans ? to : from;
+          cooColIndex[k] = isTrans ? from : to;
+          cooVal[k] = val;
+          ++k;
+          p = nl ? nl + 1 : e;
+        }
+      });
+      for (auto& x : th) x.join();
+    }
+    size_t good = std::min<size_t>(first[T], (size_t)declared);
+    for (int t = 0; t < T; ++t)
+      if (badAt[t] >= 0) { good = std::min<size_t>(good, (size_t)badAt[t]); break; }
+    top = (int)good;
   }
-  fclose(fp);
+  free(buf);
   nnz = top;
+  lastParseMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return 0;
 }
 

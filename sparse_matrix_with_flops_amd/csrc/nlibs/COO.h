@@ -15,7 +15,11 @@ class COO {
   // SNAP edge lists and MatrixMarket coordinate files (nlibs/COO.cc:48-158): '#'/'%' comment lines, then a size line
   // "rows nnz" or "rows cols nnz", then "from to [value]" lines; a 5-token '%' banner marks MatrixMarket (1-based
   // indices, "symmetric" expands (i,j)->(j,i)); isTrans reads the transpose (what R-MCL wants).
+  // The edge lines are parsed by all host threads (SMF_PARSE_THREADS overrides the count); lastParseMs / lastParseThreads
+  // describe the latest call (read + parse, wall clock).
   int readSNAPFile(const char fname[], bool isTrans = true);
+  static double lastParseMs;
+  static int lastParseThreads;
   void addSelfLoopIfNeeded();           // nlibs/COO.cc:160-188
   void makeOrdered() const;             // nlibs/COO.cc:222-235: sort by (row, col)
   int orderedAndDuplicatesRemoving();   // nlibs/COO.cc:237-266: sort + sum duplicates

@@ -1,6 +1,7 @@
 #include "qrmcl.h"
 #include "gpus/gpu_csr_kernel.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 
@@ -18,11 +19,18 @@ CSR RMCL(const char iname[], int maxIters, RunOptions runOptions) {
     exit(-1);
   }
   COO cooAt;
+  typedef std::chrono::steady_clock clk;
+  auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
   cooAt.readSNAPFile(iname);                     // isTrans = true: R-MCL works on the transpose
+  printf("time pass readSNAPFile (read + parse, %d threads) = %lf\n", COO::lastParseThreads, COO::lastParseMs);
+  auto t0 = clk::now();
   CSR Mt = rmclInit(cooAt);
   cooAt.dispose();
   CSR Mgt = Mt.deepCopy();
+  printf("time pass rmclInit = %lf\n", ms_since(t0));
+  t0 = clk::now();
   gpuRmclIter(maxIters, Mgt, Mt);
+  printf("time pass gpuRmclIter (H2D + %d device iterations + D2H) = %lf\n", maxIters, ms_since(t0));
   Mgt.dispose();
   return Mt;
 }

@@ -114,15 +114,15 @@ def test_fused_expand_prune_every_kernel(n, big, sym, monkeypatch):
     assert all(r > 0 for r in st["bin_rows"][:8]) and (st["bin_rows"][8] > 0) == big, st["bin_rows"]
     assert (st["nnzC"] == -1) == (not sym)                                # -1: nnz of the product not computed
     got = po.CSRHost(rp.cpu().numpy(), ci.cpu().numpy(), v.cpu().numpy(), m, n)
-    # rows of more than 512 product entries: the kept sum alone adds thousands of float32 terms in another order than
-    # the sequential CPU loop (measured worst 5.6e-6 on rows of ~6000 entries); all other rows at the 3e-6 of the step
-    ndiff, ties, want = assert_rmcl_step(got, A, B, what=f"fused step, n={n}", rel_long=(512, 2e-5))
+    # every row at the 3e-6 of the step; rows of more than 512 product entries against the float64 evaluation of the row
+    # rule (the oracle's sequential float32 kept sum is itself off by up to n*eps/2: helpers.assert_rmcl_step)
+    ndiff, ties, want = assert_rmcl_step(got, A, B, what=f"fused step, n={n}")
     print(f"n={n}: bins {st['bin_rows']}, {ndiff} rows differ ({ties} tie rows), nnz {got.nnz} vs {want.nnz}")
     # and the two-step path agrees with the same oracle on the same inputs
     rp2, ci2, v2 = eng.expand_prune(dA, dB, fused=False)
     torch.cuda.synchronize()
     got2 = po.CSRHost(rp2.cpu().numpy(), ci2.cpu().numpy(), v2.cpu().numpy(), m, n)
-    assert_rmcl_step(got2, A, B, what=f"two-step, n={n}", rel_long=(512, 2e-5))
+    assert_rmcl_step(got2, A, B, what=f"two-step, n={n}")
 
 
 def test_fused_and_two_step_loops_agree(monkeypatch):
@@ -175,9 +175,10 @@ def test_config4_rmcl_500k_nodes_ten_iterations():
         assert abs(int(nxt.nnz) - g["nnz"]) <= 5e-4 * g["nnz"] + 64 * (total_ties + 1)
 
 
-def test_sharded_rmcl_single_rank_matches_gpuRmclIter():
-    """dist.ShardedRMCL at world size 1 (device-resident loop: hip_gpuSpMM + hip_rmcl_prune per step, torch tensors
-    as the replicated Mt) against hip_gpuRmclIter on the same graph."""
+def test_sharded_rmcl_single_rank_steps_match_the_oracle():
+    """dist.ShardedRMCL at world size 1 (device-resident loop on torch tensors as the replicated Mt): every iteration is
+    checked from the loop's own previous state with assert_rmcl_step -- identical rows at 3e-6 except counted threshold
+    ties -- and the final state against hip_gpuRmclIter up to the ties seen on the way."""
     import torch
     from sparse_matrix_with_flops_amd.dist import HipEngine, ShardedRMCL
     A = synth_csr(12000, 57, 2)
@@ -185,18 +186,22 @@ def test_sharded_rmcl_single_rank_matches_gpuRmclIter():
     Mt = po.rmcl_init(A.rows, A.cols, A.colInd, ri, np.ones_like(A.values))
     host = (Mt.rowPtr, Mt.colInd, Mt.values, Mt.rows, Mt.cols)
     job = ShardedRMCL(HipEngine(0), host, host)
-    job.iterate(3)
-    rp, ci, v = job.result_host()
-    torch.cuda.synchronize()
+    cur, flipped = Mt, 0
+    for k in range(3):
+        job.iterate(1)
+        rp, ci, v = job.result_host()
+        torch.cuda.synchronize()
+        nxt = po.CSRHost(rp, ci, v, Mt.rows, Mt.cols)
+        ndiff, ties, _ = assert_rmcl_step(nxt, Mt, cur, what=f"sharded loop, world 1, iteration {k + 1}")
+        flipped += ndiff
+        cur = nxt
     want = hs.gpuRmclIter(3, to_hs(Mt), to_hs(Mt))
-    gl, wl = np.diff(rp), np.diff(want.rowPtr)
-    assert np.mean(gl != wl) < 1e-3 and abs(len(ci) - want.nnz) <= max(20, want.nnz // 2000)
-    rs = np.add.reduceat(v, rp[:-1][gl > 0])
-    assert np.allclose(rs, 1.0, atol=1e-4)
-    agree = 0
-    for r in np.nonzero(gl == wl)[0][:1000]:          # a threshold tie may swap one entry of a row; most rows are identical
-        agree += np.array_equal(np.sort(ci[rp[r]:rp[r + 1]]), np.sort(want.colInd[want.rowPtr[r]:want.rowPtr[r + 1]]))
-    assert agree >= 990
+    if flipped == 0:                                  # no tie flipped on the way: the two loops hold the same matrix
+        wr, wc, wv = ordered(want)
+        gr, gc, gv = ordered(cur)
+        assert np.array_equal(gr, wr) and np.array_equal(gc, wc) and np.allclose(gv, wv, rtol=1e-5, atol=0.0)
+    else:
+        assert abs(cur.nnz - want.nnz) <= 64 * flipped
 
 
 def test_cpp_mirror_runs_the_reference_test_protocol():
@@ -276,4 +281,4 @@ def test_fused_expand_prune_random_rectangular(seed):
     rp, ci, v = eng.expand_prune(dA, dB)
     torch.cuda.synchronize()
     got = po.CSRHost(rp.cpu().numpy(), ci.cpu().numpy(), v.cpu().numpy(), m, n)
-    assert_rmcl_step(got, A, B, what=f"seed {seed}", rel_long=(512, 2e-5))
+    assert_rmcl_step(got, A, B, what=f"seed {seed}")
