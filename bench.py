@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--workload", default="synth_1m_16", choices=sorted(WORKLOADS))
     ap.add_argument("--no-verify", action="store_true", help="skip the parity gate against the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the host-array entry point (hip_CSR_SpMM) timing")
     ap.add_argument("--no-gather", action="store_true",
                     help="N>1: leave C row-sharded (no allgatherv inside the timed step)")
     ap.add_argument("--chunks", type=int, default=4, help="N>1: sub-blocks per rank whose exchange overlaps the next one's numeric phase")
@@ -315,6 +316,19 @@ def main():
                            f"reference's 4-argument wrapper, {len(times)} runs (first = warm-up), median {best * 1e3:.1f} ms; "
                            f"OpenMP threads={int(threads)} of host cpus={ncpu}"),
                 "ms": round(best * 1e3, 2)}
+        if world == 1 and not args.no_host_api:
+            # the drop-in a reference caller of CSR::*spmm gets (nlibs/CSR.cc:122-134): host arrays in, malloc()ed host
+            # arrays out.  PCIe-inclusive, never `value`.
+            out = None
+            hA = hs.CSR.from_arrays(rp, ci, v, m, m)
+            runs = hs.host_api_timed(hA, hA, reps=3)
+            best = min(runs[1:], key=lambda r_: r_["ms_total"])          # first run: pinned slots are allocated
+            result["host_api"] = {
+                "entry": "hip_CSR_SpMM (host CSR in, malloc()ed host CSR out)", "ms": round(best["ms_total"], 2),
+                "ms_h2d": round(best["ms_h2d"], 2), "ms_device": round(best["ms_device"], 2), "ms_d2h": round(best["ms_d2h"], 2),
+                "GB_h2d": round(best["bytes_h2d"] / 1e9, 3), "GB_d2h": round(best["bytes_d2h"] / 1e9, 3),
+                "d2h_GBs": round(best["bytes_d2h"] / max(best["ms_d2h"], 1e-9) / 1e6, 1),
+                "GFLOPs_incl_pcie": round(2.0 * P / (best["ms_total"] * 1e-3) / 1e9, 2), "runs_ms": [round(r_["ms_total"], 1) for r_ in runs]}
         if not args.no_verify and (world == 1 or gather):
             want = po.omp_spmm(A, A)
             got = po.CSRHost(rpc, jc_h, cv_h, m, m)

@@ -97,6 +97,15 @@ int hip_CSR_SpMM(const int* IA, const int* JA, const float* A, int nnzA,
                  int** IC, int** JC, float** C, int* nnzC,
                  int m, int k, int n);
 
+/* wall-clock phases of the latest hip_CSR_SpMM of this process: upload of the operands, the device SpGEMM (hip_gpuSpMM),
+ * download of C into the malloc()ed arrays.  Both copies run on 8 threads x 2 pinned 4 MB slots each (pageable memory at
+ * PCIe rate, the page faults of the fresh output arrays spread over the threads). */
+typedef struct spgemm_host_api_stats {
+  float ms_h2d, ms_device, ms_d2h, ms_total;
+  long long bytes_h2d, bytes_d2h;
+} spgemm_host_api_stats;
+int spgemm_hip_host_api_stats(spgemm_host_api_stats* out);
+
 /* ---- (2) device-resident in, device-resident out ----------------------------------------------
  * Replaces CSR gpuSpMMWrapper(const CSR& dA, const CSR& dB)  (nlibs/gpus/gpu_csr_kernel.h:6,
  * gpu_csr_kernel.cu:128-173).  All d* pointers are device memory.  *dIC (m+1), *dJC, *dC are
@@ -191,6 +200,60 @@ int hip_gpuRmclIter(int maxIter, int rows, int cols,
                     const int* gIA, const int* gJA, const float* gA, int gnnz,
                     const int* tIA, const int* tJA, const float* tA, int tnnz,
                     int** oIA, int** oJA, float** oA, int* onnz);
+
+/* ---- multi-GPU (north_star: "partition A by row blocks across up to 8 GPUs with B replicated and a
+ * final RCCL allgatherv of C's row segments over xGMI") ----------------------------------------------------------------
+ * The reference has no multi-device code; its GPU R-MCL entry is the single call gpuRmclIter(maxIter, Mgt, Mt)
+ * (nlibs/gpus/gpu_csr_kernel.cu:281-311, dispatched from nlibs/qrmcl.cc:149-152) and its CPU path cuts rows into
+ * contiguous ranges of equal flops for its threads (arrayEqualPartition64, nlibs/tools/util.cc:123-135, used by
+ * flops_omp_CSR_SpMM, nlibs/flops_csr_kernel.cc:59-63).  The same cut is made here across GPUs.
+ *
+ * A group is a set of shards, each with its own device, handle and stream.
+ *   spgemm_hip_group_create       all shards in THIS process: shard i on devices[i] (NULL: i modulo the device count).
+ *                                 Several shards may share a device (logical shards: how a one-GPU box runs the whole
+ *                                 sharded path).  transport: how the row segments of the result travel between shards.
+ *   spgemm_hip_unique_id +        one process per GPU (torchrun, MPI, ...): rank 0 makes an id (128 bytes), the caller
+ *   spgemm_hip_group_create_rank  hands it to every rank by whatever channel it has, every rank creates its one-shard
+ *                                 group; the exchange runs over RCCL inside this library.
+ * hip_gpuRmclIter uses a group over all visible devices on its own when there is more than one. */
+#define SPGEMM_XCHG_AUTO  0   /* RCCL when every shard has its own device and librccl loads, else PEER            */
+#define SPGEMM_XCHG_RCCL  1   /* grouped ncclSend/ncclRecv per peer (full xGMI mesh: every segment on its own link) */
+#define SPGEMM_XCHG_PEER  2   /* hipMemcpyPeerAsync between the shards' devices (d2d copies on a shared device)    */
+#define SPGEMM_XCHG_HOST  3   /* staged through pinned host memory                                                 */
+#define SPGEMM_UNIQUE_ID_BYTES 128
+typedef struct spgemm_group spgemm_group;
+typedef struct spgemm_sharded spgemm_sharded;
+int spgemm_hip_group_create(spgemm_group** g, int nshards, const int* devices, int transport);
+int spgemm_hip_unique_id(void* id128);
+int spgemm_hip_group_create_rank(spgemm_group** g, int nranks, int rank, int device, const void* id128);
+int spgemm_hip_group_info(const spgemm_group* g, int* nranks, int* nlocal, int* transport);
+int spgemm_hip_group_destroy(spgemm_group* g);
+
+/* Row-sharded C = A*B with the operands resident: HOST CSR arrays in (every process of a multi-process group passes the
+ * same full A and B; B == NULL means B = A), rows of A cut into nranks contiguous blocks of equal flops
+ * (arrayEqualPartition64), block r uploaded to shard r, B replicated.  One step = per-row flops, binning, symbolic,
+ * numeric on every shard (the single-GPU pipeline, each shard's numeric phase writing straight into its slice of the
+ * gathered arrays) and, with gather != 0, the allgatherv after which EVERY shard holds the whole C.
+ * *nnzC = nnz of the gathered C (gather = 0: entries held by this process's shards), *totalP = products of the whole job.
+ * hip_sharded_spmm_result copies what local shard `local_shard` holds to malloc()ed host arrays (*rows = its row count:
+ * m when gathered, the block's rows otherwise).  hip_sharded_spmm_info: the row cut ends[nranks+1] and the last step's
+ * compute (slowest local shard, HIP events) and exchange (wall clock) times. */
+int hip_sharded_spmm_create(spgemm_group* g, const int* IA, const int* JA, const float* A, int nnzA,
+                            const int* IB, const int* JB, const float* B, int nnzB, int m, int k, int n,
+                            spgemm_sharded** job);
+int hip_sharded_spmm_step(spgemm_sharded* job, int gather, long long* nnzC, long long* totalP);
+int hip_sharded_spmm_result(spgemm_sharded* job, int local_shard, int** IC, int** JC, float** C, int* nnzC, int* rows);
+int hip_sharded_spmm_info(spgemm_sharded* job, int* ends, float* ms_compute, float* ms_exchange);
+int hip_sharded_spmm_destroy(spgemm_sharded* job);
+
+/* gpuRmclIter over a group: Mgt's row blocks (cut by the flops of the first expansion) stay resident per shard, Mt is
+ * replicated; every iteration a shard expands AND prunes its own rows (hip_rmcl_expand_prune), then the pruned blocks are
+ * gathered into the next replicated Mt -- what crosses xGMI is the pruned matrix.  Host CSRs in, malloc()ed host CSR out
+ * (every process of a multi-process group gets the whole result). */
+int hip_gpuRmclIter_sharded(spgemm_group* g, int maxIter, int rows, int cols,
+                            const int* gIA, const int* gJA, const float* gA, int gnnz,
+                            const int* tIA, const int* tJA, const float* tA, int tnnz,
+                            int** oIA, int** oJA, float** oA, int* onnz);
 
 /* ---- the step in front of the path: COO -> CSR on device arrays -------------
  * Replaces COO::addSelfLoopIfNeeded (nlibs/COO.cc:160-188), COO::makeOrdered / orderedAndDuplicatesRemoving

@@ -1,0 +1,712 @@
+// sharded.hpp — multi-GPU behind the C ABI (included at the end of spgemm_hip.hip; uses its pool / handle / phases).
+//
+// The reference has no multi-device code; its GPU R-MCL entry is ONE call,
+// gpuRmclIter(maxIter, Mgt, Mt) (nlibs/gpus/gpu_csr_kernel.cu:281-311, dispatched from nlibs/qrmcl.cc:149-152), and its
+// CPU path cuts rows into contiguous ranges of equal flops for its threads (arrayEqualPartition64,
+// nlibs/tools/util.cc:123-135, used by flops_omp_CSR_SpMM, nlibs/flops_csr_kernel.cc:59-63).  Here the same cut is made
+// across GPUs: shard s owns the rows [ends[s], ends[s+1]) of A (or of Mgt), B (or Mt) is replicated, every shard runs the
+// single-GPU pipeline on its block with its own handle/stream, and the row segments of the result are exchanged so that
+// every shard ends up with the whole C (allgatherv).  For R-MCL each shard prunes its rows BEFORE the exchange: what
+// crosses xGMI is the pruned matrix, which is also the next iteration's replicated operand.
+//
+// A GROUP is a set of shards.  In-process (spgemm_hip_group_create): all shards live in this process, one per device
+// -- or several LOGICAL shards on one device, which is how the whole path is tested on a one-GPU box.  Multi-process
+// (spgemm_hip_group_create_rank): one local shard per process, one process per GPU, wired with an RCCL unique id that
+// the caller distributes (torchrun / MPI / a file).  Transports of the exchange:
+//   RCCL  grouped ncclSend/ncclRecv per peer (xGMI is a full mesh: every segment travels its own link, no ring).  The
+//         library loads librccl at run time (dlopen; no link-time dependency).  Shards must sit on distinct devices;
+//         a group of one rank exchanges with itself through RCCL (exercises the transport on one GPU).
+//   PEER  hipMemcpyPeerAsync between the shards' devices (in-process only; plain d2d copies when shards share a device).
+//   HOST  staged through pinned host memory (in-process only; SURVEY.md 8e "replicas only" fallback).
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <string>
+#include <thread>
+
+namespace {
+
+struct RcclApi {
+  void* so = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string why;
+  bool ok = false;
+};
+
+RcclApi& rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* env = getenv("SPGEMM_RCCL_LIB");
+    // absolute paths first: a process that also hosts PyTorch already has the wheel's own librccl (linked against the
+    // wheel's HIP runtime) loaded under the same soname; this library talks to the system runtime and wants the system RCCL
+    const char* cand[] = {env, "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"};
+    for (const char* c : cand) {
+      if (!c || !c[0]) continue;
+      api.so = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+      if (api.so) break;
+      api.why = dlerror();
+    }
+    if (!api.so) return;
+#define SMF_SYM(field, name)                                                                  \
+  api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.so, name));                     \
+  if (!api.field) { api.why = std::string("missing symbol ") + name; return; }
+    SMF_SYM(GetUniqueId, "ncclGetUniqueId") SMF_SYM(CommInitRank, "ncclCommInitRank") SMF_SYM(CommDestroy, "ncclCommDestroy")
+    SMF_SYM(GroupStart, "ncclGroupStart") SMF_SYM(GroupEnd, "ncclGroupEnd") SMF_SYM(Send, "ncclSend") SMF_SYM(Recv, "ncclRecv")
+    SMF_SYM(AllGather, "ncclAllGather") SMF_SYM(GetErrorString, "ncclGetErrorString")
+#undef SMF_SYM
+    api.ok = true;
+  });
+  return api;
+}
+
+#define NCCLCHK(expr)                                                                                              \
+  do {                                                                                                             \
+    ncclResult_t r__ = (expr);                                                                                     \
+    if (r__ != ncclSuccess) return fail(SPGEMM_ERR_HIP, "%s failed: %s", #expr, rccl().GetErrorString(r__));       \
+  } while (0)
+
+__global__ void k_offset_copy(int n, const int* __restrict__ src, int off, int* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i] + off;
+}
+
+struct DevCSR {                                   // a device CSR owned by the pool of `device`
+  int* I = nullptr; int* J = nullptr; float* V = nullptr;
+  int rows = 0, cols = 0, nnz = 0;
+};
+
+}  // namespace
+
+struct spgemm_shard {
+  int device = 0;
+  int grank = 0;                                  // global rank of this shard
+  spgemm_handle* h = nullptr;
+  ncclComm_t comm = nullptr;
+  long long* dSizes = nullptr;                    // nranks int64 on the device (multi-process size exchange)
+  long long* hSizes = nullptr;                    // pinned twin
+  std::string err;                                // message of a failure inside this shard's worker thread
+  int rc = 0;
+};
+
+struct spgemm_group {
+  int nranks = 0;                                 // shards of the whole job
+  int transport = SPGEMM_XCHG_PEER;
+  std::vector<spgemm_shard> sh;                   // LOCAL shards (all of them in-process, one in multi-process mode)
+  bool all_local() const { return (int)sh.size() == nranks; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// group life cycle
+// ------------------------------------------------------------------------------------------------
+static int group_init_comms(spgemm_group* g, const ncclUniqueId& id) {
+  RcclApi& R = rccl();
+  if (!R.ok) return fail(SPGEMM_ERR_HIP, "RCCL is not available: %s", R.why.c_str());
+  NCCLCHK(R.GroupStart());
+  for (auto& s : g->sh) {
+    HIPCHK(hipSetDevice(s.device));
+    ncclResult_t r = R.CommInitRank(&s.comm, g->nranks, id, s.grank);
+    if (r != ncclSuccess) { R.GroupEnd(); return fail(SPGEMM_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", s.grank, g->nranks, R.GetErrorString(r)); }
+  }
+  NCCLCHK(R.GroupEnd());
+  return SPGEMM_OK;
+}
+
+static int group_make_shards(spgemm_group* g) {
+  for (auto& s : g->sh) {
+    CHK(spgemm_hip_create(&s.h, s.device));
+    HIPCHK(hipSetDevice(s.device));
+    HIPCHK(hipMalloc((void**)&s.dSizes, sizeof(long long) * (size_t)g->nranks));
+    HIPCHK(hipHostMalloc((void**)&s.hSizes, sizeof(long long) * (size_t)g->nranks, hipHostMallocDefault));
+  }
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_hip_group_destroy(spgemm_group* g) {
+  if (!g) return SPGEMM_OK;
+  for (auto& s : g->sh) {
+    hipSetDevice(s.device);
+    if (s.comm && rccl().ok) rccl().CommDestroy(s.comm);
+    hipFree(s.dSizes);
+    hipHostFree(s.hSizes);
+    spgemm_hip_destroy(s.h);
+  }
+  delete g;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_hip_group_create(spgemm_group** out, int nshards, const int* devices, int transport) {
+  if (!out) return fail(SPGEMM_ERR_ARG, "group out-pointer is null");
+  *out = nullptr;
+  if (nshards < 1 || nshards > 64) return fail(SPGEMM_ERR_ARG, "nshards=%d out of range [1,64]", nshards);
+  if (transport < SPGEMM_XCHG_AUTO || transport > SPGEMM_XCHG_HOST) return fail(SPGEMM_ERR_ARG, "unknown transport %d", transport);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(SPGEMM_ERR_NODEVICE, "no HIP device visible: libspgemm_hip has no CPU fallback");
+  spgemm_group* g = new spgemm_group();
+  g->nranks = nshards;
+  g->sh.resize((size_t)nshards);
+  bool distinct = true;
+  for (int i = 0; i < nshards; ++i) {
+    const int d = devices ? devices[i] : i % ndev;
+    if (d < 0 || d >= ndev) { delete g; return fail(SPGEMM_ERR_ARG, "shard %d: device %d out of range [0,%d)", i, d, ndev); }
+    g->sh[i].device = d;
+    g->sh[i].grank = i;
+    for (int j = 0; j < i; ++j) distinct = distinct && g->sh[j].device != d;
+  }
+  if (transport == SPGEMM_XCHG_RCCL && !distinct) { delete g; return fail(SPGEMM_ERR_ARG, "the RCCL transport needs every shard on its own device"); }
+  if (transport == SPGEMM_XCHG_AUTO) transport = (distinct && nshards > 1 && rccl().ok) ? SPGEMM_XCHG_RCCL : SPGEMM_XCHG_PEER;
+  g->transport = transport;
+  int rc = group_make_shards(g);
+  if (rc == SPGEMM_OK && transport == SPGEMM_XCHG_RCCL) {
+    RcclApi& R = rccl();
+    if (!R.ok) rc = fail(SPGEMM_ERR_HIP, "RCCL is not available: %s", R.why.c_str());
+    else {
+      ncclUniqueId id;
+      ncclResult_t r = R.GetUniqueId(&id);
+      if (r != ncclSuccess) rc = fail(SPGEMM_ERR_HIP, "ncclGetUniqueId failed: %s", R.GetErrorString(r));
+      else rc = group_init_comms(g, id);
+    }
+  }
+  if (rc) { spgemm_hip_group_destroy(g); return rc; }
+  *out = g;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_hip_unique_id(void* id128) {
+  if (!id128) return fail(SPGEMM_ERR_ARG, "id buffer is null");
+  static_assert(sizeof(ncclUniqueId) == SPGEMM_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");
+  RcclApi& R = rccl();
+  if (!R.ok) return fail(SPGEMM_ERR_HIP, "RCCL is not available: %s", R.why.c_str());
+  ncclUniqueId id;
+  NCCLCHK(R.GetUniqueId(&id));
+  memcpy(id128, &id, sizeof(id));
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_hip_group_create_rank(spgemm_group** out, int nranks, int rank, int device, const void* id128) {
+  if (!out) return fail(SPGEMM_ERR_ARG, "group out-pointer is null");
+  *out = nullptr;
+  if (nranks < 1 || rank < 0 || rank >= nranks || !id128) return fail(SPGEMM_ERR_ARG, "bad rank %d of %d / null id", rank, nranks);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(SPGEMM_ERR_NODEVICE, "no HIP device visible: libspgemm_hip has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(SPGEMM_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+  spgemm_group* g = new spgemm_group();
+  g->nranks = nranks;
+  g->transport = SPGEMM_XCHG_RCCL;
+  g->sh.resize(1);
+  g->sh[0].device = device;
+  g->sh[0].grank = rank;
+  int rc = group_make_shards(g);
+  if (rc == SPGEMM_OK) {
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    rc = group_init_comms(g, id);
+  }
+  if (rc) { spgemm_hip_group_destroy(g); return rc; }
+  *out = g;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_hip_group_info(const spgemm_group* g, int* nranks, int* nlocal, int* transport) {
+  if (!g) return fail(SPGEMM_ERR_ARG, "null group");
+  if (nranks) *nranks = g->nranks;
+  if (nlocal) *nlocal = (int)g->sh.size();
+  if (transport) *transport = g->transport;
+  return SPGEMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// helpers shared by the sharded SpGEMM and the sharded R-MCL
+// ------------------------------------------------------------------------------------------------
+// arrayEqualPartition64 (nlibs/tools/util.cc:123-135): prefix = exclusive scan of the per-row flops, prefix[n] = total;
+// part p owns rows [ends[p], ends[p+1]); every part but the last gets at least one row while rows remain.
+static void equal_partition64(const std::vector<long long>& prefix, int parts, std::vector<int>& ends) {
+  const int n = (int)prefix.size() - 1;
+  const long long total = prefix[n];
+  const long long chunk = (total + parts - 1) / parts;
+  ends.assign((size_t)parts + 1, 0);
+  int now = 0;
+  for (int i = 0; i < parts - 1; ++i) {
+    const long long target = std::min<long long>((long long)(i + 1) * chunk, total);
+    const int upper = (int)(std::upper_bound(prefix.begin() + now, prefix.begin() + n + 1, target) - prefix.begin());
+    int e = std::max(upper - 1, now + 1);
+    e = std::min(e, n);
+    ends[i + 1] = e;
+    now = e;
+  }
+  ends[parts] = n;
+}
+
+static void host_row_flops_prefix(const int* IA, const int* JA, const int* IB, int m, std::vector<long long>& prefix) {
+  prefix.assign((size_t)m + 1, 0);
+  for (int i = 0; i < m; ++i) {
+    long long f = 0;
+    for (int p = IA[i]; p < IA[i + 1]; ++p) f += IB[JA[p] + 1] - IB[JA[p]];
+    prefix[i + 1] = prefix[i] + f;
+  }
+}
+
+// run fn(local shard index) for every local shard, concurrently when there are several; collects the first failure
+template <class F>
+static int for_each_shard(spgemm_group* g, F&& fn) {
+  const int n = (int)g->sh.size();
+  auto body = [&](int i) {
+    spgemm_shard& s = g->sh[i];
+    s.rc = fn(i);
+    s.err = s.rc ? spgemm_hip_last_error() : "";
+  };
+  if (n == 1) body(0);
+  else {
+    std::vector<std::thread> th;
+    for (int i = 0; i < n; ++i) th.emplace_back(body, i);
+    for (auto& t : th) t.join();
+  }
+  for (int i = 0; i < n; ++i)
+    if (g->sh[i].rc) return fail(g->sh[i].rc, "shard %d (device %d): %s", g->sh[i].grank, g->sh[i].device, g->sh[i].err.c_str());
+  return SPGEMM_OK;
+}
+
+static int upload_csr(int device, const int* I, const int* J, const float* V, int r0, int r1, int cols, DevCSR* out) {
+  HIPCHK(hipSetDevice(device));
+  const int rows = r1 - r0;
+  const int base = I[r0], nnz = I[r1] - base;
+  out->rows = rows; out->cols = cols; out->nnz = nnz;
+  HIPCHK(pool().alloc((void**)&out->I, sizeof(int) * ((size_t)rows + 1)));
+  HIPCHK(pool().alloc((void**)&out->J, sizeof(int) * (size_t)std::max(nnz, 1)));
+  HIPCHK(pool().alloc((void**)&out->V, sizeof(float) * (size_t)std::max(nnz, 1)));
+  std::vector<int> rp((size_t)rows + 1);
+  for (int i = 0; i <= rows; ++i) rp[i] = I[r0 + i] - base;
+  HIPCHK(hipMemcpy(out->I, rp.data(), sizeof(int) * ((size_t)rows + 1), hipMemcpyHostToDevice));
+  if (nnz > 0) {
+    HIPCHK(hipMemcpy(out->J, J + base, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(out->V, V + base, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice));
+  }
+  return SPGEMM_OK;
+}
+static void free_csr(int device, DevCSR* c) {
+  hipSetDevice(device);
+  pool().release(c->I); pool().release(c->J); pool().release(c->V);
+  c->I = c->J = nullptr; c->V = nullptr; c->nnz = 0;
+}
+
+// per-rank entry counts -> every rank knows all of them.  In-process: they are all in this process's memory.
+// Multi-process: one ncclAllGather of an int64 per rank.
+static int exchange_sizes(spgemm_group* g, const std::vector<long long>& localCounts, std::vector<long long>& all) {
+  all.assign((size_t)g->nranks, 0);
+  if (g->all_local()) {
+    for (size_t i = 0; i < g->sh.size(); ++i) all[(size_t)g->sh[i].grank] = localCounts[i];
+    return SPGEMM_OK;
+  }
+  RcclApi& R = rccl();
+  spgemm_shard& s = g->sh[0];
+  HIPCHK(hipSetDevice(s.device));
+  s.hSizes[0] = localCounts[0];
+  HIPCHK(hipMemcpyAsync(s.dSizes + s.grank, s.hSizes, sizeof(long long), hipMemcpyHostToDevice, s.h->stream));
+  NCCLCHK(R.AllGather(s.dSizes + s.grank, s.dSizes, 1, ncclInt64, s.comm, s.h->stream));
+  HIPCHK(hipMemcpyAsync(s.hSizes, s.dSizes, sizeof(long long) * (size_t)g->nranks, hipMemcpyDeviceToHost, s.h->stream));
+  HIPCHK(hipStreamSynchronize(s.h->stream));
+  for (int r = 0; r < g->nranks; ++r) all[(size_t)r] = s.hSizes[r];
+  return SPGEMM_OK;
+}
+
+// The allgatherv.  Every local shard holds full-size arrays gI[m+1], gJ[total], gV[total] in which ITS OWN segment is
+// already in place: rows [ends[r], ends[r+1]) of gI (global offsets; the last rank also wrote gI[m]) and entries
+// [offs[r], offs[r+1]) of gJ / gV.  After the call every shard holds every segment.
+struct GatherView { int* gI; int* gJ; float* gV; };
+static int allgatherv_segments(spgemm_group* g, const std::vector<int>& ends, const std::vector<long long>& offs,
+                               int m, const std::vector<GatherView>& view) {
+  const int G = g->nranks;
+  auto rows_of = [&](int r) { return (size_t)(ends[r + 1] - ends[r]) + (r == G - 1 ? 1u : 0u); };   // the last rank carries gI[m]
+  auto cnt_of = [&](int r) { return (size_t)(offs[r + 1] - offs[r]); };
+  (void)m;
+  if (g->transport == SPGEMM_XCHG_RCCL) {
+    RcclApi& R = rccl();
+    if (G == 1) {
+      // a group of one rank has nobody to exchange with; its segment makes the round trip through RCCL all the same
+      // (ncclSend to itself, ncclRecv into scratch, scratch copied back over the segment), so that a one-GPU box
+      // exercises the transport and a broken one shows up as a wrong C
+      spgemm_shard& s = g->sh[0];
+      const GatherView& v = view[0];
+      HIPCHK(hipSetDevice(s.device));
+      int* tI = nullptr; int* tJ = nullptr; float* tV = nullptr;
+      auto done = [&](int rc) { pool().release(tI); pool().release(tJ); pool().release(tV); return rc; };
+      if (pool().alloc((void**)&tI, sizeof(int) * std::max<size_t>(rows_of(0), 1)) != hipSuccess ||
+          pool().alloc((void**)&tJ, sizeof(int) * std::max<size_t>(cnt_of(0), 1)) != hipSuccess ||
+          pool().alloc((void**)&tV, sizeof(float) * std::max<size_t>(cnt_of(0), 1)) != hipSuccess)
+        return done(fail(SPGEMM_ERR_HIP, "scratch allocation for the self exchange failed"));
+      ncclResult_t r = R.GroupStart();
+      if (r == ncclSuccess && rows_of(0)) r = R.Send(v.gI, rows_of(0), ncclInt32, 0, s.comm, s.h->stream);
+      if (r == ncclSuccess && rows_of(0)) r = R.Recv(tI, rows_of(0), ncclInt32, 0, s.comm, s.h->stream);
+      if (r == ncclSuccess && cnt_of(0)) r = R.Send(v.gJ, cnt_of(0), ncclInt32, 0, s.comm, s.h->stream);
+      if (r == ncclSuccess && cnt_of(0)) r = R.Recv(tJ, cnt_of(0), ncclInt32, 0, s.comm, s.h->stream);
+      if (r == ncclSuccess && cnt_of(0)) r = R.Send(v.gV, cnt_of(0), ncclFloat32, 0, s.comm, s.h->stream);
+      if (r == ncclSuccess && cnt_of(0)) r = R.Recv(tV, cnt_of(0), ncclFloat32, 0, s.comm, s.h->stream);
+      const ncclResult_t r2 = R.GroupEnd();
+      if (r != ncclSuccess || r2 != ncclSuccess)
+        return done(fail(SPGEMM_ERR_HIP, "RCCL self exchange failed: %s", R.GetErrorString(r != ncclSuccess ? r : r2)));
+      if (hipMemcpyAsync(v.gI, tI, sizeof(int) * rows_of(0), hipMemcpyDeviceToDevice, s.h->stream) != hipSuccess ||
+          hipMemcpyAsync(v.gJ, tJ, sizeof(int) * cnt_of(0), hipMemcpyDeviceToDevice, s.h->stream) != hipSuccess ||
+          hipMemcpyAsync(v.gV, tV, sizeof(float) * cnt_of(0), hipMemcpyDeviceToDevice, s.h->stream) != hipSuccess ||
+          hipStreamSynchronize(s.h->stream) != hipSuccess)
+        return done(fail(SPGEMM_ERR_HIP, "RCCL self exchange: copy back failed: %s", hipGetErrorString(hipGetLastError())));
+      return done(SPGEMM_OK);
+    }
+    NCCLCHK(R.GroupStart());
+    for (size_t li = 0; li < g->sh.size(); ++li) {
+      spgemm_shard& s = g->sh[li];
+      const GatherView& v = view[li];
+      const int me = s.grank;
+      HIPCHK(hipSetDevice(s.device));
+      for (int p = 0; p < G; ++p) {
+        if (p == me) continue;
+        // my segment to p, p's segment from p: three messages per peer and direction, all inside ONE group, so RCCL
+        // runs them concurrently -- every pair of GPUs has its own xGMI link
+        ncclResult_t r = ncclSuccess;
+        if (r == ncclSuccess && rows_of(me)) r = R.Send(v.gI + ends[me], rows_of(me), ncclInt32, p, s.comm, s.h->stream);
+        if (r == ncclSuccess && cnt_of(me)) r = R.Send(v.gJ + offs[me], cnt_of(me), ncclInt32, p, s.comm, s.h->stream);
+        if (r == ncclSuccess && cnt_of(me)) r = R.Send(v.gV + offs[me], cnt_of(me), ncclFloat32, p, s.comm, s.h->stream);
+        if (r == ncclSuccess && rows_of(p)) r = R.Recv(v.gI + ends[p], rows_of(p), ncclInt32, p, s.comm, s.h->stream);
+        if (r == ncclSuccess && cnt_of(p)) r = R.Recv(v.gJ + offs[p], cnt_of(p), ncclInt32, p, s.comm, s.h->stream);
+        if (r == ncclSuccess && cnt_of(p)) r = R.Recv(v.gV + offs[p], cnt_of(p), ncclFloat32, p, s.comm, s.h->stream);
+        if (r != ncclSuccess) { R.GroupEnd(); return fail(SPGEMM_ERR_HIP, "ncclSend/ncclRecv failed: %s", R.GetErrorString(r)); }
+      }
+    }
+    NCCLCHK(R.GroupEnd());
+    for (auto& s : g->sh) { HIPCHK(hipSetDevice(s.device)); HIPCHK(hipStreamSynchronize(s.h->stream)); }
+    return SPGEMM_OK;
+  }
+  if (!g->all_local()) return fail(SPGEMM_ERR_ARG, "a multi-process group exchanges over RCCL only");
+  if (g->transport == SPGEMM_XCHG_PEER) {
+    for (size_t d = 0; d < g->sh.size(); ++d) {          // pull: the destination's stream copies from every source
+      spgemm_shard& dst = g->sh[d];
+      HIPCHK(hipSetDevice(dst.device));
+      for (size_t q = 0; q < g->sh.size(); ++q) {
+        if (q == d) continue;
+        spgemm_shard& src = g->sh[q];
+        const int r = src.grank;
+        auto cp = [&](void* to, const void* from, size_t bytes) -> hipError_t {
+          if (!bytes) return hipSuccess;
+          if (src.device == dst.device) return hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, dst.h->stream);
+          return hipMemcpyPeerAsync(to, dst.device, from, src.device, bytes, dst.h->stream);
+        };
+        HIPCHK(cp(view[d].gI + ends[r], view[q].gI + ends[r], rows_of(r) * sizeof(int)));
+        HIPCHK(cp(view[d].gJ + offs[r], view[q].gJ + offs[r], cnt_of(r) * sizeof(int)));
+        HIPCHK(cp(view[d].gV + offs[r], view[q].gV + offs[r], cnt_of(r) * sizeof(float)));
+      }
+    }
+    for (auto& s : g->sh) { HIPCHK(hipSetDevice(s.device)); HIPCHK(hipStreamSynchronize(s.h->stream)); }
+    return SPGEMM_OK;
+  }
+  // HOST: every segment once to pinned host memory, then to every other shard
+  size_t need = 0;
+  for (int r = 0; r < G; ++r) need = std::max(need, std::max(rows_of(r) * sizeof(int), cnt_of(r) * sizeof(float)));
+  void* stage = nullptr;
+  HIPCHK(hipHostMalloc(&stage, std::max<size_t>(need, 16), hipHostMallocDefault));
+  auto bounce = [&](size_t q, int which) -> int {
+    spgemm_shard& src = g->sh[q];
+    const int r = src.grank;
+    const size_t bytes = which == 0 ? rows_of(r) * sizeof(int) : cnt_of(r) * 4;
+    if (!bytes) return SPGEMM_OK;
+    auto at = [&](const GatherView& v) -> char* {
+      return which == 0 ? (char*)(v.gI + ends[r]) : which == 1 ? (char*)(v.gJ + offs[r]) : (char*)(v.gV + offs[r]);
+    };
+    HIPCHK(hipSetDevice(src.device));
+    HIPCHK(hipMemcpy(stage, at(view[q]), bytes, hipMemcpyDeviceToHost));
+    for (size_t d = 0; d < g->sh.size(); ++d) {
+      if (d == q) continue;
+      HIPCHK(hipSetDevice(g->sh[d].device));
+      HIPCHK(hipMemcpy(at(view[d]), stage, bytes, hipMemcpyHostToDevice));
+    }
+    return SPGEMM_OK;
+  };
+  int rc = SPGEMM_OK;
+  for (size_t q = 0; q < g->sh.size() && !rc; ++q)
+    for (int which = 0; which < 3 && !rc; ++which) rc = bounce(q, which);
+  hipHostFree(stage);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sharded SpGEMM job: operands resident, one step = SpGEMM on every shard + allgatherv of C
+// ------------------------------------------------------------------------------------------------
+struct spgemm_sharded {
+  spgemm_group* g = nullptr;
+  int m = 0, k = 0, n = 0;
+  bool sameB = false;
+  std::vector<int> ends;                          // row cut, nranks+1
+  long long totalP = 0;
+  struct Local {
+    DevCSR A;                                     // this shard's row block of A
+    DevCSR B;                                     // replica of B
+    int* lIC = nullptr;                           // local rowPtr of the block (m_s + 1)
+    int* gI = nullptr; int* gJ = nullptr; float* gV = nullptr;   // gathered C (or the block alone when not gathered)
+    size_t capC = 0;
+    long long nnz = 0;                            // entries the arrays hold after the last step
+    bool gathered = false;
+  };
+  std::vector<Local> loc;
+  float ms_compute = 0.f, ms_exchange = 0.f;      // last step: slowest local shard's device time; wall time of the exchange
+};
+
+extern "C" int hip_sharded_spmm_destroy(spgemm_sharded* job) {
+  if (!job) return SPGEMM_OK;
+  for (size_t i = 0; i < job->loc.size(); ++i) {
+    const int dev = job->g->sh[i].device;
+    auto& L = job->loc[i];
+    free_csr(dev, &L.A);
+    free_csr(dev, &L.B);
+    hipSetDevice(dev);
+    pool().release(L.lIC); pool().release(L.gI); pool().release(L.gJ); pool().release(L.gV);
+  }
+  delete job;
+  return SPGEMM_OK;
+}
+
+extern "C" int hip_sharded_spmm_create(spgemm_group* g, const int* IA, const int* JA, const float* A, int nnzA,
+                                       const int* IB, const int* JB, const float* B, int nnzB, int m, int k, int n,
+                                       spgemm_sharded** out) {
+  if (!out) return fail(SPGEMM_ERR_ARG, "job out-pointer is null");
+  *out = nullptr;
+  if (!g) return fail(SPGEMM_ERR_ARG, "null group");
+  if (m < 0 || k < 0 || n < 0) return fail(SPGEMM_ERR_ARG, "negative dimension");
+  CHK(check_common(IA, JA, A, nnzA, "A"));
+  const bool same = !IB || (IB == IA && JB == JA && B == A);
+  if (same) { IB = IA; JB = JA; B = A; nnzB = nnzA; if (m != k) return fail(SPGEMM_ERR_ARG, "B omitted but A is not square"); }
+  CHK(check_common(IB, JB, B, nnzB, "B"));
+  CHK(validate_host_csr(IA, JA, m, k, nnzA, "A"));
+  if (!same) CHK(validate_host_csr(IB, JB, k, n, nnzB, "B"));
+  spgemm_sharded* job = new spgemm_sharded();
+  job->g = g; job->m = m; job->k = k; job->n = n; job->sameB = same;
+  std::vector<long long> prefix;
+  host_row_flops_prefix(IA, JA, IB, m, prefix);
+  job->totalP = prefix[(size_t)m];
+  equal_partition64(prefix, g->nranks, job->ends);
+  job->loc.resize(g->sh.size());
+  int rc = for_each_shard(g, [&](int i) -> int {
+    spgemm_shard& s = g->sh[i];
+    auto& L = job->loc[i];
+    const int r0 = job->ends[s.grank], r1 = job->ends[s.grank + 1];
+    CHK(upload_csr(s.device, IA, JA, A, r0, r1, k, &L.A));
+    CHK(upload_csr(s.device, IB, JB, B, 0, k, n, &L.B));
+    HIPCHK(pool().alloc((void**)&L.lIC, sizeof(int) * ((size_t)(r1 - r0) + 1)));
+    HIPCHK(pool().alloc((void**)&L.gI, sizeof(int) * ((size_t)m + 1)));
+    CHK(ws_ensure(s.h, r1 - r0));
+    return SPGEMM_OK;
+  });
+  if (rc) { hip_sharded_spmm_destroy(job); return rc; }
+  *out = job;
+  return SPGEMM_OK;
+}
+
+static int ensure_cap(spgemm_sharded::Local& L, size_t entries) {
+  if (entries <= L.capC && L.gJ) return SPGEMM_OK;
+  pool().release(L.gJ); pool().release(L.gV);
+  L.gJ = nullptr; L.gV = nullptr; L.capC = 0;
+  const size_t cap = entries + entries / 16 + 1024;
+  HIPCHK(pool().alloc((void**)&L.gJ, sizeof(int) * cap));
+  HIPCHK(pool().alloc((void**)&L.gV, sizeof(float) * cap));
+  L.capC = cap;
+  return SPGEMM_OK;
+}
+
+extern "C" int hip_sharded_spmm_step(spgemm_sharded* job, int gather, long long* nnzC, long long* totalP) {
+  if (!job) return fail(SPGEMM_ERR_ARG, "null job");
+  spgemm_group* g = job->g;
+  const int G = g->nranks;
+  std::vector<long long> localNnz(g->sh.size(), 0), all;
+  // phase 1 on every shard: classification + symbolic of its block
+  CHK(for_each_shard(g, [&](int i) -> int {
+    spgemm_shard& s = g->sh[i];
+    auto& L = job->loc[i];
+    HIPCHK(hipSetDevice(s.device));
+    int nz = 0;
+    CHK(symbolic_phase(s.h, L.A.I, L.A.J, L.A.nnz, L.B.I, L.B.J, L.A.rows, job->k, job->n, nullptr, L.lIC, &nz));
+    localNnz[i] = nz;
+    return SPGEMM_OK;
+  }));
+  if (gather && G > 1) CHK(exchange_sizes(g, localNnz, all));
+  else { all.assign((size_t)G, 0); for (size_t i = 0; i < g->sh.size(); ++i) all[(size_t)g->sh[i].grank] = localNnz[i]; }
+  std::vector<long long> offs((size_t)G + 1, 0);
+  for (int r = 0; r < G; ++r) offs[(size_t)r + 1] = offs[(size_t)r] + all[(size_t)r];
+  const bool doGather = gather != 0;
+  const long long total = doGather ? offs[(size_t)G] : 0;
+  if (doGather && total > 0x7fffffffLL) return fail(SPGEMM_ERR_OVERFLOW, "nnz(C)=%lld does not fit int32 CSR", total);
+  // phase 2: numeric straight into the shard's slice of the gathered arrays; rowPtr with the global offset
+  CHK(for_each_shard(g, [&](int i) -> int {
+    spgemm_shard& s = g->sh[i];
+    auto& L = job->loc[i];
+    HIPCHK(hipSetDevice(s.device));
+    const long long off = doGather ? offs[(size_t)s.grank] : 0;
+    CHK(ensure_cap(L, (size_t)std::max<long long>(doGather ? total : localNnz[i], 1)));
+    CHK(numeric_phase(s.h, L.A.I, L.A.J, L.A.V, L.B.I, L.B.J, L.B.V, L.A.rows, job->n, L.lIC, L.gJ + off, L.gV + off));
+    const int r0 = doGather ? job->ends[s.grank] : 0;
+    const int cnt = L.A.rows + ((!doGather || s.grank == G - 1) ? 1 : 0);
+    if (cnt > 0) hipLaunchKernelGGL(k_offset_copy, dim3(cdiv(cnt, 256)), dim3(256), 0, s.h->stream, cnt, L.lIC, (int)off, L.gI + r0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s.h->stream));
+    L.nnz = doGather ? total : localNnz[i];
+    L.gathered = doGather;
+    return SPGEMM_OK;
+  }));
+  float ms = 0.f;
+  for (auto& s : g->sh) ms = std::max(ms, s.h->stats.ms_total);
+  job->ms_compute = ms;
+  job->ms_exchange = 0.f;
+  if (doGather && (G > 1 || g->transport == SPGEMM_XCHG_RCCL)) {
+    std::vector<GatherView> view(g->sh.size());
+    for (size_t i = 0; i < g->sh.size(); ++i) view[i] = GatherView{job->loc[i].gI, job->loc[i].gJ, job->loc[i].gV};
+    const auto t0 = std::chrono::steady_clock::now();
+    CHK(allgatherv_segments(g, job->ends, offs, job->m, view));
+    job->ms_exchange = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  long long sum = 0;
+  for (long long v : all) sum += v;
+  if (nnzC) *nnzC = doGather ? total : sum;           // not gathered: the entries held by this process's shards
+  if (totalP) *totalP = job->totalP;
+  return SPGEMM_OK;
+}
+
+extern "C" int hip_sharded_spmm_result(spgemm_sharded* job, int local_shard, int** IC, int** JC, float** C, int* nnzC, int* rows) {
+  if (!job || !IC || !JC || !C || !nnzC) return fail(SPGEMM_ERR_ARG, "null argument");
+  if (local_shard < 0 || local_shard >= (int)job->loc.size()) return fail(SPGEMM_ERR_ARG, "local shard %d out of range", local_shard);
+  auto& L = job->loc[(size_t)local_shard];
+  HIPCHK(hipSetDevice(job->g->sh[(size_t)local_shard].device));
+  const int nr = L.gathered ? job->m : L.A.rows;
+  const size_t nz = (size_t)L.nnz;
+  int* hI = (int*)malloc(sizeof(int) * ((size_t)nr + 1));
+  int* hJ = (int*)malloc(sizeof(int) * std::max<size_t>(nz, 1));
+  float* hV = (float*)malloc(sizeof(float) * std::max<size_t>(nz, 1));
+  if (!hI || !hJ || !hV) { free(hI); free(hJ); free(hV); return fail(SPGEMM_ERR_NOMEM, "host malloc of C failed"); }
+  if (hipMemcpy(hI, L.gI, sizeof(int) * ((size_t)nr + 1), hipMemcpyDeviceToHost) != hipSuccess ||
+      (nz && hipMemcpy(hJ, L.gJ, sizeof(int) * nz, hipMemcpyDeviceToHost) != hipSuccess) ||
+      (nz && hipMemcpy(hV, L.gV, sizeof(float) * nz, hipMemcpyDeviceToHost) != hipSuccess)) {
+    free(hI); free(hJ); free(hV);
+    return fail(SPGEMM_ERR_HIP, "copy of C to the host failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  *IC = hI; *JC = hJ; *C = hV; *nnzC = (int)nz;
+  if (rows) *rows = nr;
+  return SPGEMM_OK;
+}
+
+extern "C" int hip_sharded_spmm_info(spgemm_sharded* job, int* ends, float* ms_compute, float* ms_exchange) {
+  if (!job) return fail(SPGEMM_ERR_ARG, "null job");
+  if (ends) for (size_t i = 0; i < job->ends.size(); ++i) ends[i] = job->ends[i];
+  if (ms_compute) *ms_compute = job->ms_compute;
+  if (ms_exchange) *ms_exchange = job->ms_exchange;
+  return SPGEMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sharded R-MCL: Mgt's row blocks stay resident per shard, Mt is replicated; per iteration every shard expands and
+// PRUNES its own rows (hip_rmcl_expand_prune), then the pruned blocks are gathered into the next replicated Mt.
+// ------------------------------------------------------------------------------------------------
+extern "C" int hip_gpuRmclIter_sharded(spgemm_group* g, int maxIter, int rows, int cols,
+                                       const int* gIA, const int* gJA, const float* gA, int gnnz,
+                                       const int* tIA, const int* tJA, const float* tA, int tnnz,
+                                       int** oIA, int** oJA, float** oA, int* onnz) {
+  if (!oIA || !oJA || !oA || !onnz) return fail(SPGEMM_ERR_ARG, "output pointer is null");
+  if (!g) return fail(SPGEMM_ERR_ARG, "null group");
+  if (rows < 0 || cols != rows || maxIter < 0) return fail(SPGEMM_ERR_ARG, "R-MCL needs a square matrix and maxIter >= 0");
+  CHK(check_common(gIA, gJA, gA, gnnz, "Mgt"));
+  CHK(check_common(tIA, tJA, tA, tnnz, "Mt"));
+  CHK(validate_host_csr(gIA, gJA, rows, cols, gnnz, "Mgt"));
+  CHK(validate_host_csr(tIA, tJA, rows, cols, tnnz, "Mt"));
+  const int G = g->nranks, m = rows;
+  // the cut: flops of the first expansion (the blocks stay where they are for all iterations)
+  std::vector<long long> prefix;
+  host_row_flops_prefix(gIA, gJA, tIA, m, prefix);
+  std::vector<int> ends;
+  equal_partition64(prefix, G, ends);
+  struct Local { DevCSR Mg; DevCSR Mt; int* pI = nullptr; int* pJ = nullptr; float* pV = nullptr; int pn = 0; };
+  std::vector<Local> loc(g->sh.size());
+  auto cleanup = [&](int rc) {
+    for (size_t i = 0; i < loc.size(); ++i) {
+      const int dev = g->sh[i].device;
+      free_csr(dev, &loc[i].Mg); free_csr(dev, &loc[i].Mt);
+      hipSetDevice(dev);
+      pool().release(loc[i].pI); pool().release(loc[i].pJ); pool().release(loc[i].pV);
+    }
+    return rc;
+  };
+  int rc = for_each_shard(g, [&](int i) -> int {
+    spgemm_shard& s = g->sh[i];
+    CHK(upload_csr(s.device, gIA, gJA, gA, ends[s.grank], ends[s.grank + 1], cols, &loc[i].Mg));
+    CHK(upload_csr(s.device, tIA, tJA, tA, 0, rows, cols, &loc[i].Mt));
+    return SPGEMM_OK;
+  });
+  if (rc) return cleanup(rc);
+  for (int it = 0; it < maxIter; ++it) {
+    std::vector<long long> localNnz(g->sh.size(), 0), all;
+    rc = for_each_shard(g, [&](int i) -> int {
+      spgemm_shard& s = g->sh[i];
+      Local& L = loc[i];
+      HIPCHK(hipSetDevice(s.device));
+      CHK(hip_rmcl_expand_prune(s.h, L.Mg.I, L.Mg.J, L.Mg.V, L.Mg.nnz, L.Mt.I, L.Mt.J, L.Mt.V, L.Mt.nnz,
+                                L.Mg.rows, cols, cols, &L.pI, &L.pJ, &L.pV, &L.pn));
+      localNnz[i] = L.pn;
+      return SPGEMM_OK;
+    });
+    if (rc) return cleanup(rc);
+    if ((rc = exchange_sizes(g, localNnz, all))) return cleanup(rc);
+    std::vector<long long> offs((size_t)G + 1, 0);
+    for (int r = 0; r < G; ++r) offs[(size_t)r + 1] = offs[(size_t)r] + all[(size_t)r];
+    const long long total = offs[(size_t)G];
+    if (total > 0x7fffffffLL) return cleanup(fail(SPGEMM_ERR_OVERFLOW, "nnz(Mt)=%lld does not fit int32 CSR", total));
+    std::vector<GatherView> view(g->sh.size());
+    rc = for_each_shard(g, [&](int i) -> int {          // the next Mt: own pruned block in place, global row offsets
+      spgemm_shard& s = g->sh[i];
+      Local& L = loc[i];
+      HIPCHK(hipSetDevice(s.device));
+      DevCSR N;
+      N.rows = rows; N.cols = cols; N.nnz = (int)total;
+      HIPCHK(pool().alloc((void**)&N.I, sizeof(int) * ((size_t)m + 1)));
+      HIPCHK(pool().alloc((void**)&N.J, sizeof(int) * (size_t)std::max<long long>(total, 1)));
+      HIPCHK(pool().alloc((void**)&N.V, sizeof(float) * (size_t)std::max<long long>(total, 1)));
+      const long long off = offs[(size_t)s.grank];
+      const int cnt = L.Mg.rows + (s.grank == G - 1 ? 1 : 0);
+      if (cnt > 0) hipLaunchKernelGGL(k_offset_copy, dim3(cdiv(cnt, 256)), dim3(256), 0, s.h->stream, cnt, L.pI, (int)off, N.I + ends[s.grank]);
+      if (L.pn > 0) {
+        HIPCHK(hipMemcpyAsync(N.J + off, L.pJ, sizeof(int) * (size_t)L.pn, hipMemcpyDeviceToDevice, s.h->stream));
+        HIPCHK(hipMemcpyAsync(N.V + off, L.pV, sizeof(float) * (size_t)L.pn, hipMemcpyDeviceToDevice, s.h->stream));
+      }
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(s.h->stream));
+      pool().release(L.pI); pool().release(L.pJ); pool().release(L.pV);
+      L.pI = L.pJ = nullptr; L.pV = nullptr;
+      free_csr(s.device, &L.Mt);
+      L.Mt = N;
+      view[i] = GatherView{N.I, N.J, N.V};
+      return SPGEMM_OK;
+    });
+    if (rc) return cleanup(rc);
+    if (G > 1 || g->transport == SPGEMM_XCHG_RCCL)
+      if ((rc = allgatherv_segments(g, ends, offs, m, view))) return cleanup(rc);
+  }
+  // every shard holds the whole Mt; the first local one brings it to the host
+  Local& L0 = loc[0];
+  if (hipSetDevice(g->sh[0].device) != hipSuccess) return cleanup(fail(SPGEMM_ERR_HIP, "hipSetDevice failed"));
+  const int nz = L0.Mt.nnz;
+  int* hI = (int*)malloc(sizeof(int) * ((size_t)rows + 1));
+  int* hJ = (int*)malloc(sizeof(int) * (size_t)std::max(nz, 1));
+  float* hA = (float*)malloc(sizeof(float) * (size_t)std::max(nz, 1));
+  if (!hI || !hJ || !hA) { free(hI); free(hJ); free(hA); return cleanup(fail(SPGEMM_ERR_NOMEM, "host malloc failed")); }
+  if (hipMemcpy(hI, L0.Mt.I, sizeof(int) * ((size_t)rows + 1), hipMemcpyDeviceToHost) != hipSuccess ||
+      (nz && hipMemcpy(hJ, L0.Mt.J, sizeof(int) * (size_t)nz, hipMemcpyDeviceToHost) != hipSuccess) ||
+      (nz && hipMemcpy(hA, L0.Mt.V, sizeof(float) * (size_t)nz, hipMemcpyDeviceToHost) != hipSuccess)) {
+    free(hI); free(hJ); free(hA);
+    return cleanup(fail(SPGEMM_ERR_HIP, "copy of Mt to the host failed: %s", hipGetErrorString(hipGetLastError())));
+  }
+  *oIA = hI; *oJA = hJ; *oA = hA; *onnz = nz;
+  return cleanup(SPGEMM_OK);
+}

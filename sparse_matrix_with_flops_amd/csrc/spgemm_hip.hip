@@ -6,6 +6,7 @@
 #include "../../include/spgemm_hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -13,6 +14,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 using namespace smf;
@@ -197,6 +199,7 @@ struct spgemm_handle {
   int bhMargin = 125;                // parking region per hash class, % of products/npass (SPGEMM_BHMARGIN; tests force overflows)
   int h1sym = 32;                    // blocks per CU of the wave-per-row symbolic kernel (SPGEMM_H1SYM, experiments)
   spgemm_stats stats;
+  spgemm_host_api_stats host_api = {};   // phases of the latest hip_CSR_SpMM
 };
 
 static std::mutex g_count_mu;
@@ -970,6 +973,106 @@ static int validate_host_csr(const int* I, const int* J, int rows, int cols, int
   return SPGEMM_OK;
 }
 
+// Pageable host memory <-> device at PCIe speed.  The caller's arrays are plain malloc memory (the reference's
+// CSR::dispose() is free(), nlibs/CSR.h:323-327), and for the outputs they are fresh: a blocking hipMemcpy moves them
+// through the runtime's single staging thread (page faults of 1.8 GB of untouched memory included) at a fraction of the
+// link rate.  Here T threads each own a contiguous slice, a private stream and two pinned 4 MB slots: while one slot is
+// on the link the thread moves the other between slot and destination, so the faults and the memcpy of the slices run
+// in parallel and the link stays busy.  Slots are allocated once per process.
+namespace {
+struct CopyLanes {
+  static constexpr int T = 8;
+  static constexpr size_t SLOT = size_t(4) << 20;
+  char* slot[T][2] = {};
+  hipStream_t st[T] = {};
+  int device = -1;
+  std::mutex mu;
+  int ensure(int dev) {
+    if (device == dev && slot[0][0]) return SPGEMM_OK;
+    release();
+    for (int t = 0; t < T; ++t) {
+      HIPCHK(hipStreamCreateWithFlags(&st[t], hipStreamNonBlocking));
+      for (int b = 0; b < 2; ++b) HIPCHK(hipHostMalloc((void**)&slot[t][b], SLOT, hipHostMallocDefault));
+    }
+    device = dev;
+    return SPGEMM_OK;
+  }
+  void release() {
+    for (int t = 0; t < T; ++t) {
+      for (int b = 0; b < 2; ++b) { if (slot[t][b]) hipHostFree(slot[t][b]); slot[t][b] = nullptr; }
+      if (st[t]) hipStreamDestroy(st[t]);
+      st[t] = nullptr;
+    }
+    device = -1;
+  }
+};
+CopyLanes& lanes() { static CopyLanes* l = new CopyLanes(); return *l; }
+
+// one thread's slice; toDevice: host -> device, else device -> host
+hipError_t lane_copy(int dev, hipStream_t st, char* const slots[2], char* host, char* devp, size_t bytes, bool toDevice) {
+  hipError_t e = hipSetDevice(dev);
+  if (e != hipSuccess) return e;
+  const size_t S = CopyLanes::SLOT;
+  const size_t n = (bytes + S - 1) / S;
+  if (toDevice) {
+    for (size_t c = 0; c < n; ++c) {
+      const size_t off = c * S, len = std::min(S, bytes - off);
+      char* sl = slots[c & 1];
+      if (c >= 2 && (e = hipStreamSynchronize(st)) != hipSuccess) return e;   // (both slots' earlier copies are done)
+      memcpy(sl, host + off, len);
+      if ((e = hipMemcpyAsync(devp + off, sl, len, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    }
+    return hipStreamSynchronize(st);
+  }
+  size_t pendOff = 0, pendLen = 0;
+  int pendSlot = -1;
+  for (size_t c = 0; c < n; ++c) {
+    const size_t off = c * S, len = std::min(S, bytes - off);
+    if ((e = hipMemcpyAsync(slots[c & 1], devp + off, len, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if (pendSlot >= 0) memcpy(host + pendOff, slots[pendSlot], pendLen);      // the previous chunk, already landed
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    pendOff = off; pendLen = len; pendSlot = (int)(c & 1);
+  }
+  if (pendSlot >= 0) memcpy(host + pendOff, slots[pendSlot], pendLen);
+  return hipSuccess;
+}
+}  // namespace
+
+// several (host, device, bytes) pairs in one go: the bytes of all of them are dealt to the lanes in 4 MB chunks
+struct CopyJob { void* host; void* dev; size_t bytes; };
+static int copy_pageable(int dev, const CopyJob* jobs, int njobs, bool toDevice) {
+  size_t total = 0;
+  for (int i = 0; i < njobs; ++i) total += jobs[i].bytes;
+  if (!total) return SPGEMM_OK;
+  if (total < (size_t(1) << 20)) {                       // small: not worth the threads
+    for (int i = 0; i < njobs; ++i)
+      if (jobs[i].bytes) HIPCHK(toDevice ? hipMemcpy(jobs[i].dev, jobs[i].host, jobs[i].bytes, hipMemcpyHostToDevice)
+                                        : hipMemcpy(jobs[i].host, jobs[i].dev, jobs[i].bytes, hipMemcpyDeviceToHost));
+    return SPGEMM_OK;
+  }
+  CopyLanes& L = lanes();
+  std::lock_guard<std::mutex> lk(L.mu);
+  CHK(L.ensure(dev));
+  // cut every job into T slices (all lanes work on the same job at the same time: neighbouring pages, one job after the other)
+  hipError_t errs[CopyLanes::T];
+  std::vector<std::thread> th;
+  for (int t = 0; t < CopyLanes::T; ++t) {
+    errs[t] = hipSuccess;
+    th.emplace_back([&, t] {
+      for (int i = 0; i < njobs && errs[t] == hipSuccess; ++i) {
+        const size_t b = jobs[i].bytes;
+        const size_t per = ((b + CopyLanes::T - 1) / CopyLanes::T + 4095) & ~size_t(4095);
+        const size_t lo = std::min(b, per * (size_t)t), hi = std::min(b, lo + per);
+        if (hi > lo) errs[t] = lane_copy(dev, L.st[t], L.slot[t], (char*)jobs[i].host + lo, (char*)jobs[i].dev + lo, hi - lo, toDevice);
+      }
+    });
+  }
+  for (auto& x : th) x.join();
+  for (int t = 0; t < CopyLanes::T; ++t)
+    if (errs[t] != hipSuccess) return fail(SPGEMM_ERR_HIP, "pipelined %s copy failed: %s", toDevice ? "h2d" : "d2h", hipGetErrorString(errs[t]));
+  return SPGEMM_OK;
+}
+
 extern "C" int hip_CSR_SpMM(const int* IA, const int* JA, const float* A, int nnzA, const int* IB, const int* JB,
                             const float* B, int nnzB, int** IC, int** JC, float** C, int* nnzC, int m, int k, int n) {
   if (!IC || !JC || !C || !nnzC) return fail(SPGEMM_ERR_ARG, "output pointer is null");
@@ -981,6 +1084,7 @@ extern "C" int hip_CSR_SpMM(const int* IA, const int* JA, const float* A, int nn
   CHK(validate_host_csr(IB, JB, k, n, nnzB, "B"));
   spgemm_handle* h = nullptr;
   CHK(default_handle(&h));
+  HIPCHK(hipSetDevice(h->device));
   int *dIA = nullptr, *dJA = nullptr, *dIB = nullptr, *dJB = nullptr, *dIC = nullptr, *dJC = nullptr;
   float *dA = nullptr, *dB = nullptr, *dC = nullptr;
   int *hIC = nullptr, *hJC = nullptr;
@@ -992,9 +1096,13 @@ extern "C" int hip_CSR_SpMM(const int* IA, const int* JA, const float* A, int nn
     return rc;
   };
   const bool same = (IA == IB && JA == JB && A == B && nnzA == nnzB && m == k);  // C = A*A: upload once
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t).count(); };
   int rc;
+  std::vector<CopyJob> up;
 #define UP(dst, src, bytes)                                                                        \
-  if ((rc = spgemm_hip_malloc((void**)&dst, (bytes))) || (rc = spgemm_hip_memcpy_h2d(dst, src, (bytes)))) return cleanup(rc);
+  if ((rc = spgemm_hip_malloc((void**)&dst, (bytes)))) return cleanup(rc);                          \
+  up.push_back(CopyJob{(void*)(src), (void*)dst, (size_t)(bytes)});
   UP(dIA, IA, sizeof(int) * ((size_t)m + 1));
   UP(dJA, JA, sizeof(int) * (size_t)nnzA);
   UP(dA, A, sizeof(float) * (size_t)nnzA);
@@ -1004,21 +1112,39 @@ extern "C" int hip_CSR_SpMM(const int* IA, const int* JA, const float* A, int nn
     UP(dB, B, sizeof(float) * (size_t)nnzB);
   }
 #undef UP
+  if ((rc = copy_pageable(h->device, up.data(), (int)up.size(), true))) return cleanup(rc);
+  h->host_api.ms_h2d = ms_since(t0);
+  const auto t1 = std::chrono::steady_clock::now();
   int nz = 0;
   rc = hip_gpuSpMM(h, dIA, dJA, dA, nnzA, same ? dIA : dIB, same ? dJA : dJB, same ? dA : dB, nnzB, m, k, n, &dIC,
                    &dJC, &dC, &nz);
   if (rc) return cleanup(rc);
+  h->host_api.ms_device = ms_since(t1);
+  const auto t2 = std::chrono::steady_clock::now();
   // outputs must be malloc()ed: the caller's CSR::dispose() is free() (nlibs/CSR.h:323-327)
   hIC = (int*)malloc(sizeof(int) * ((size_t)m + 1));
   hJC = (int*)malloc(sizeof(int) * (size_t)std::max(nz, 1));
   hC = (float*)malloc(sizeof(float) * (size_t)std::max(nz, 1));
   if (!hIC || !hJC || !hC) return cleanup(fail(SPGEMM_ERR_NOMEM, "host malloc of C failed"));
-  if ((rc = spgemm_hip_memcpy_d2h(hIC, dIC, sizeof(int) * ((size_t)m + 1))) ||
-      (rc = spgemm_hip_memcpy_d2h(hJC, dJC, sizeof(int) * (size_t)nz)) ||
-      (rc = spgemm_hip_memcpy_d2h(hC, dC, sizeof(float) * (size_t)nz)))
-    return cleanup(rc);
+  const CopyJob down[3] = {{hIC, dIC, sizeof(int) * ((size_t)m + 1)}, {hJC, dJC, sizeof(int) * (size_t)nz},
+                           {hC, dC, sizeof(float) * (size_t)nz}};
+  if ((rc = copy_pageable(h->device, down, 3, false))) return cleanup(rc);
+  h->host_api.ms_d2h = ms_since(t2);
+  h->host_api.ms_total = ms_since(t0);
+  h->host_api.bytes_h2d = 0;
+  for (auto& j : up) h->host_api.bytes_h2d += (long long)j.bytes;
+  h->host_api.bytes_d2h = (long long)(down[0].bytes + down[1].bytes + down[2].bytes);
   *IC = hIC; *JC = hJC; *C = hC; *nnzC = nz;
   return cleanup(SPGEMM_OK);
+}
+
+// phases of the latest hip_CSR_SpMM (host arrays in, host arrays out) on the default handle
+extern "C" int spgemm_hip_host_api_stats(spgemm_host_api_stats* out) {
+  if (!out) return fail(SPGEMM_ERR_ARG, "null argument");
+  spgemm_handle* h = nullptr;
+  CHK(default_handle(&h));
+  *out = h->host_api;
+  return SPGEMM_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1207,6 +1333,13 @@ extern "C" int hip_rmcl_expand_prune(spgemm_handle* h, const int* dIA, const int
   return SPGEMM_OK;
 }
 
+struct spgemm_group;
+extern "C" int spgemm_hip_group_create(spgemm_group** out, int nshards, const int* devices, int transport);
+extern "C" int spgemm_hip_group_destroy(spgemm_group* g);
+extern "C" int hip_gpuRmclIter_sharded(spgemm_group* g, int maxIter, int rows, int cols, const int* gIA, const int* gJA,
+                                       const float* gA, int gnnz, const int* tIA, const int* tJA, const float* tA, int tnnz,
+                                       int** oIA, int** oJA, float** oA, int* onnz);
+
 extern "C" int hip_gpuRmclIter(int maxIter, int rows, int cols, const int* gIA, const int* gJA, const float* gA, int gnnz,
                                const int* tIA, const int* tJA, const float* tA, int tnnz, int** oIA, int** oJA,
                                float** oA, int* onnz) {
@@ -1216,6 +1349,27 @@ extern "C" int hip_gpuRmclIter(int maxIter, int rows, int cols, const int* gIA, 
   CHK(check_common(tIA, tJA, tA, tnnz, "Mt"));
   CHK(validate_host_csr(gIA, gJA, rows, cols, gnnz, "Mgt"));
   CHK(validate_host_csr(tIA, tJA, rows, cols, tnnz, "Mt"));
+  {
+    // More than one device visible: Mgt's rows are cut into flops-balanced blocks, one per GPU, Mt is replicated and the
+    // pruned blocks are gathered every iteration (sharded.hpp) -- behind the same call the reference's driver makes
+    // (nlibs/qrmcl.cc:149-152).  SPGEMM_RMCL_DEVICES limits the devices used; SPGEMM_RMCL_SHARDS asks for that many
+    // LOGICAL shards (spread round-robin over the devices: the one-GPU rehearsal of the sharded loop).
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+    int use = ndev;
+    if (const char* e = getenv("SPGEMM_RMCL_DEVICES")) use = std::max(1, std::min(ndev, atoi(e)));
+    int shards = use;
+    if (const char* e = getenv("SPGEMM_RMCL_SHARDS")) shards = std::max(1, std::min(64, atoi(e)));
+    if (shards > 1 && rows >= shards) {
+      std::vector<int> devs((size_t)shards);
+      for (int i = 0; i < shards; ++i) devs[(size_t)i] = i % std::max(use, 1);
+      spgemm_group* grp = nullptr;
+      CHK(spgemm_hip_group_create(&grp, shards, devs.data(), SPGEMM_XCHG_AUTO));
+      const int rc = hip_gpuRmclIter_sharded(grp, maxIter, rows, cols, gIA, gJA, gA, gnnz, tIA, tJA, tA, tnnz, oIA, oJA, oA, onnz);
+      spgemm_hip_group_destroy(grp);
+      return rc;
+    }
+  }
   spgemm_handle* h = nullptr;
   CHK(default_handle(&h));
   int *dgI = nullptr, *dgJ = nullptr, *dtI = nullptr, *dtJ = nullptr;
@@ -1310,3 +1464,8 @@ extern "C" int spgemm_hip_selftest(spgemm_handle* h) {
 // COO -> CSR on the device (the step in front of the path)
 // ------------------------------------------------------------------------------------------------
 #include "coo_device.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU: groups of shards, sharded SpGEMM, sharded R-MCL
+// ------------------------------------------------------------------------------------------------
+#include "sharded.hpp"

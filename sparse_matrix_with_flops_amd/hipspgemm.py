@@ -36,7 +36,13 @@ EXPORTS = [
     "hip_spgemm_symbolic", "hip_spgemm_numeric", "hip_csr_row_flops", "spgemm_hip_kernel_name",
     "hip_rmcl_prune", "hip_gpuRmclIter", "hip_coo_to_csr", "hip_flopsStats", "spgemm_hip_set_kernel_timing",
     "hip_rmcl_prune_n", "hip_rmcl_expand_prune", "spgemm_hip_pool_cached_bytes", "hip_nnzStats", "hip_resultsComparison",
+    "spgemm_hip_group_create", "spgemm_hip_unique_id", "spgemm_hip_group_create_rank", "spgemm_hip_group_info",
+    "spgemm_hip_group_destroy", "hip_sharded_spmm_create", "hip_sharded_spmm_step", "hip_sharded_spmm_result",
+    "hip_sharded_spmm_info", "hip_sharded_spmm_destroy", "hip_gpuRmclIter_sharded", "spgemm_hip_host_api_stats",
 ]
+XCHG_AUTO, XCHG_RCCL, XCHG_PEER, XCHG_HOST = 0, 1, 2, 3
+XCHG_NAMES = {0: "auto", 1: "rccl", 2: "peer", 3: "host"}
+UNIQUE_ID_BYTES = 128
 
 
 class SpgemmError(RuntimeError):
@@ -45,6 +51,11 @@ class SpgemmError(RuntimeError):
 
 class BinReport(C.Structure):
     _fields_ = [("rows", C.c_int), ("rows_differ", C.c_int), ("first_bad_row", C.c_int), ("max_rel_err", C.c_double)]
+
+
+class HostApiStats(C.Structure):
+    _fields_ = [("ms_h2d", C.c_float), ("ms_device", C.c_float), ("ms_d2h", C.c_float), ("ms_total", C.c_float),
+                ("bytes_h2d", C.c_longlong), ("bytes_d2h", C.c_longlong)]
 
 
 class Stats(C.Structure):
@@ -119,6 +130,21 @@ def lib():
         L.hip_csr_sort_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.spgemm_hip_selftest.argtypes = [C.c_void_p]
         L.spgemm_hip_set_kernel_timing.argtypes = [C.c_void_p, C.c_uint]
+        host_in = [_I, _I, _F, C.c_int]
+        L.spgemm_hip_host_api_stats.argtypes = [C.POINTER(HostApiStats)]
+        L.spgemm_hip_group_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, _I, C.c_int]
+        L.spgemm_hip_unique_id.argtypes = [C.c_void_p]
+        L.spgemm_hip_group_create_rank.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.spgemm_hip_group_info.argtypes = [C.c_void_p, _I, _I, _I]
+        L.spgemm_hip_group_destroy.argtypes = [C.c_void_p]
+        L.hip_sharded_spmm_create.argtypes = [C.c_void_p] + host_in + host_in + [C.c_int, C.c_int, C.c_int,
+                                                                                   C.POINTER(C.c_void_p)]
+        L.hip_sharded_spmm_step.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        L.hip_sharded_spmm_result.argtypes = [C.c_void_p, C.c_int, C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I, _I]
+        L.hip_sharded_spmm_info.argtypes = [C.c_void_p, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.hip_sharded_spmm_destroy.argtypes = [C.c_void_p]
+        L.hip_gpuRmclIter_sharded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + host_in + host_in + \
+            [C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I]
         L.free = C.CDLL(None).free
         L.free.argtypes = [C.c_void_p]
         _lib = L
@@ -267,6 +293,28 @@ class CSR:
         for p in (ic, jc, cv):                      # CSR::dispose() == free() (nlibs/CSR.h:323-327)
             L.free(C.cast(p, C.c_void_p))
         return CSR(v, ci, rp, self.rows, B.cols, n)
+
+
+def host_api_timed(A, B, reps=3):
+    """hip_CSR_SpMM (host arrays in, malloc()ed host arrays out -- what a reference caller of CSR::*spmm gets) timed
+    around the C call alone, outputs freed unread.  -> list of per-run dicts (ms_total, ms_h2d, ms_device, ms_d2h, bytes)."""
+    import time
+    L = lib()
+    runs = []
+    for _ in range(reps):
+        ic, jc, cv, nnz = _I(), _I(), _F(), C.c_int(0)
+        t0 = time.perf_counter()
+        rc = L.hip_CSR_SpMM(*_host_args(A), *_host_args(B), C.byref(ic), C.byref(jc), C.byref(cv), C.byref(nnz),
+                            A.rows, A.cols, B.cols)
+        wall = (time.perf_counter() - t0) * 1e3
+        _check(rc, "hip_CSR_SpMM")
+        for p in (ic, jc, cv):
+            L.free(C.cast(p, C.c_void_p))
+        st = HostApiStats()
+        _check(L.spgemm_hip_host_api_stats(C.byref(st)), "spgemm_hip_host_api_stats")
+        runs.append({"ms_wall": wall, "ms_total": st.ms_total, "ms_h2d": st.ms_h2d, "ms_device": st.ms_device,
+                     "ms_d2h": st.ms_d2h, "bytes_h2d": int(st.bytes_h2d), "bytes_d2h": int(st.bytes_d2h), "nnzC": nnz.value})
+    return runs
 
 
 def _dev_args(M):
@@ -476,6 +524,128 @@ def gpuRmclIter(maxIter, Mgt, Mt):
     for p in (oi, oj, ov):
         L.free(C.cast(p, C.c_void_p))
     return CSR(v, ci, rp, Mt.rows, Mt.cols, n)
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-GPU behind the C ABI (include/spgemm_hip.h "multi-GPU"): groups of shards, sharded SpGEMM, sharded R-MCL
+# ---------------------------------------------------------------------------------------------
+def unique_id():
+    """128-byte RCCL id made by rank 0 of a multi-process job; hand it to every rank (bytes)."""
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    _check(lib().spgemm_hip_unique_id(buf), "spgemm_hip_unique_id")
+    return buf.raw
+
+
+class Group:
+    """spgemm_group.  Group(nshards, devices=None, transport=XCHG_AUTO): every shard in this process (several may share
+    a device).  Group.of_rank(nranks, rank, device, id): one process per GPU, wired with unique_id()."""
+
+    def __init__(self, nshards, devices=None, transport=XCHG_AUTO, _ptr=None):
+        self._g = C.c_void_p()
+        if _ptr is not None:
+            self._g = _ptr
+        else:
+            dv = None
+            if devices is not None:
+                dv = (C.c_int * len(devices))(*[int(d) for d in devices])
+                assert len(devices) == nshards
+            _check(lib().spgemm_hip_group_create(C.byref(self._g), int(nshards), dv, int(transport)), "spgemm_hip_group_create")
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().spgemm_hip_group_info(self._g, C.byref(a), C.byref(b), C.byref(c)), "spgemm_hip_group_info")
+        self.nranks, self.nlocal, self.transport = a.value, b.value, c.value
+
+    @staticmethod
+    def of_rank(nranks, rank, device, id128):
+        g = C.c_void_p()
+        buf = C.create_string_buffer(bytes(id128), UNIQUE_ID_BYTES)
+        _check(lib().spgemm_hip_group_create_rank(C.byref(g), int(nranks), int(rank), int(device), buf),
+               "spgemm_hip_group_create_rank")
+        return Group(nranks, _ptr=g)
+
+    @property
+    def ptr(self):
+        return self._g
+
+    def close(self):
+        if self._g:
+            lib().spgemm_hip_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _host_args(M):
+    return [M.rowPtr.ctypes.data_as(_I), M.colInd.ctypes.data_as(_I), M.values.ctypes.data_as(_F), int(M.nnz)]
+
+
+def _take_malloced(L, pi, pj, pv, rows, n):
+    rp = np.ctypeslib.as_array(pi, shape=(rows + 1,)).copy()
+    ci = np.ctypeslib.as_array(pj, shape=(n,)).copy() if n else np.zeros(0, np.int32)
+    v = np.ctypeslib.as_array(pv, shape=(n,)).copy() if n else np.zeros(0, np.float32)
+    for p in (pi, pj, pv):
+        L.free(C.cast(p, C.c_void_p))
+    return rp, ci, v
+
+
+class ShardedSpMM:
+    """spgemm_sharded: C = A*B row-sharded over a Group with the operands resident (host CSRs in; B=None means B=A)."""
+
+    def __init__(self, group, A, B=None):
+        assert not A.on_device and (B is None or not B.on_device)
+        self.group = group
+        self._keep = (A, B)
+        self._j = C.c_void_p()
+        bargs = _host_args(B) if B is not None else [None, None, None, 0]
+        _check(lib().hip_sharded_spmm_create(group.ptr, *_host_args(A), *bargs, A.rows, A.cols,
+                                             (B.cols if B is not None else A.cols), C.byref(self._j)), "hip_sharded_spmm_create")
+        self.m, self.n = A.rows, (B.cols if B is not None else A.cols)
+
+    def step(self, gather=True):
+        """-> (nnzC, total products P)"""
+        nz, P = C.c_longlong(0), C.c_longlong(0)
+        _check(lib().hip_sharded_spmm_step(self._j, int(bool(gather)), C.byref(nz), C.byref(P)), "hip_sharded_spmm_step")
+        return nz.value, P.value
+
+    def result(self, local_shard=0):
+        L = lib()
+        pi, pj, pv, n, rows = _I(), _I(), _F(), C.c_int(0), C.c_int(0)
+        _check(L.hip_sharded_spmm_result(self._j, int(local_shard), C.byref(pi), C.byref(pj), C.byref(pv), C.byref(n),
+                                         C.byref(rows)), "hip_sharded_spmm_result")
+        rp, ci, v = _take_malloced(L, pi, pj, pv, rows.value, n.value)
+        return CSR(v, ci, rp, rows.value, self.n, n.value)
+
+    def info(self):
+        ends = (C.c_int * (self.group.nranks + 1))()
+        a, b = C.c_float(0), C.c_float(0)
+        _check(lib().hip_sharded_spmm_info(self._j, ends, C.byref(a), C.byref(b)), "hip_sharded_spmm_info")
+        return {"ends": [int(x) for x in ends], "ms_compute": a.value, "ms_exchange": b.value}
+
+    def close(self):
+        if self._j:
+            lib().hip_sharded_spmm_destroy(self._j)
+            self._j = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gpuRmclIter_sharded(group, maxIter, Mgt, Mt):
+    """gpuRmclIter over a Group (hip_gpuRmclIter_sharded): returns the new Mt (host CSR)."""
+    assert not Mgt.on_device and not Mt.on_device
+    L = lib()
+    oi, oj, ov, on = _I(), _I(), _F(), C.c_int(0)
+    rc = L.hip_gpuRmclIter_sharded(group.ptr, int(maxIter), Mgt.rows, Mgt.cols, *_host_args(Mgt), *_host_args(Mt),
+                                   C.byref(oi), C.byref(oj), C.byref(ov), C.byref(on))
+    _check(rc, "hip_gpuRmclIter_sharded")
+    rp, ci, v = _take_malloced(L, oi, oj, ov, Mt.rows, on.value)
+    return CSR(v, ci, rp, Mt.rows, Mt.cols, on.value)
 
 
 def sort_rows_device(dC, handle=None):

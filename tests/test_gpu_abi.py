@@ -176,3 +176,29 @@ def test_nnzC_beyond_int32_is_refused():
     small = synth_csr(4096, 11, 2)
     got = hs.gpuSpMMWrapper(to_hs(small).toGpuCSR(), to_hs(small).toGpuCSR(), eng.handle).toCpuCSR()
     assert got.nnz == po.omp_spmm(small, small).nnz
+
+
+def test_host_array_entry_point_moves_large_arrays_through_the_copy_lanes():
+    """hip_CSR_SpMM on operands and a result far above the 1 MB below which it uses plain copies: the operands go up and
+    the malloc()ed result comes down through the 8 threads x 2 pinned slots (spgemm_hip.hip: copy_pageable) -- slices
+    that do not divide evenly, a last chunk shorter than a slot.  Full parity against the oracle, twice (slots reused),
+    and the phase statistics of the call."""
+    A = synth_csr(100003, 23, 2)                                     # odd sizes on purpose
+    want = po.omp_spmm(A, A)
+    hA = to_hs(A)
+    from helpers import assert_parity
+    for rep in range(2):
+        got = hA.hip_spmm(hA)
+        assert_parity(got, want, what=f"host API, run {rep}")
+    runs = hs.host_api_timed(hA, hA, reps=2)
+    r = runs[-1]
+    assert r["nnzC"] == want.nnz
+    assert r["bytes_d2h"] == 4 * (A.rows + 1) + 8 * want.nnz and r["bytes_h2d"] == 4 * (A.rows + 1) + 8 * A.nnz
+    assert r["ms_total"] >= r["ms_h2d"] + r["ms_device"] + r["ms_d2h"] - 0.5
+    assert r["bytes_d2h"] > (64 << 20)                               # really beyond the small-copy path
+    print(f"host API: {r['ms_total']:.1f} ms (h2d {r['ms_h2d']:.1f}, device {r['ms_device']:.1f}, d2h {r['ms_d2h']:.1f}; "
+          f"{r['bytes_d2h'] / r['ms_d2h'] / 1e6:.1f} GB/s down)")
+    # A != B: six arrays go up
+    B = synth_csr(100003, 29, 2)
+    got = hA.hip_spmm(to_hs(B))
+    assert_parity(got, po.omp_spmm(A, B), what="host API, A != B")

@@ -1,0 +1,151 @@
+"""GPU (-m gpu): multi-GPU BEHIND THE C ABI (include/spgemm_hip.h "multi-GPU"; csrc/sharded.hpp) on the one GPU of the test
+box: groups of LOGICAL shards that share the device run the whole sharded path -- flops-balanced row cut, per-shard
+handles and streams, numeric phase writing into the slice of the gathered arrays, exchange of the row segments -- over
+the transports a one-GPU box can run: PEER (device copies), HOST (staged through pinned memory) and RCCL with one rank
+(the rank's segment makes a round trip through ncclSend/ncclRecv to itself).  Results against the oracle.  What only an
+8-GPU node can show -- the RCCL exchange between different devices -- is the same code path with peers != self."""
+import numpy as np
+import pytest
+
+from helpers import assert_parity, assert_rmcl_step, po, synth_csr
+from sparse_matrix_with_flops_amd import hipspgemm as hs
+from test_gpu_parity import to_hs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import __graft_entry__ as ge
+    ge.build()
+    assert hs.device_count() >= 1
+
+
+def _graph(m, seed):
+    A = synth_csr(m, seed, 2)
+    ri = np.repeat(np.arange(A.rows, dtype=np.int32), np.diff(A.rowPtr))
+    return po.rmcl_init(A.rows, A.cols, A.colInd, ri, np.ones_like(A.values))
+
+
+@pytest.mark.parametrize("shards,transport", [(1, hs.XCHG_PEER), (2, hs.XCHG_PEER), (3, hs.XCHG_HOST), (5, hs.XCHG_PEER),
+                                              (1, hs.XCHG_RCCL)])
+def test_sharded_spmm_logical_shards(shards, transport):
+    m, seed = 40000, 19
+    A = synth_csr(m, seed, 2)
+    want = po.omp_spmm(A, A)
+    g = hs.Group(shards, devices=[0] * shards, transport=transport)
+    assert (g.nranks, g.nlocal, g.transport) == (shards, shards, transport)
+    job = hs.ShardedSpMM(g, to_hs(A))
+    for _ in range(2):                                # twice: buffers and handles are reused
+        nnz, P = job.step(gather=True)
+    flops = po.row_flops(A, A)
+    prefix = np.concatenate([[0], np.cumsum(flops)]).astype(np.int64)
+    assert P == int(prefix[-1]) and nnz == want.nnz
+    info = job.info()
+    assert np.array_equal(info["ends"], po.equal_partition64(prefix, shards))       # arrayEqualPartition64
+    for s in range(shards):                           # EVERY shard holds the whole C
+        got = job.result(s)
+        assert_parity(got, want, what=f"{shards} shards over {hs.XCHG_NAMES[transport]}, shard {s}")
+    # not gathered: every shard keeps its own block
+    nnz2, _ = job.step(gather=False)
+    assert nnz2 == want.nnz
+    ends = info["ends"]
+    for s in range(shards):
+        blk = job.result(s)
+        r0, r1 = ends[s], ends[s + 1]
+        assert blk.rows == r1 - r0
+        sub = po.CSRHost(want.rowPtr[r0:r1 + 1] - want.rowPtr[r0], want.colInd[want.rowPtr[r0]:want.rowPtr[r1]],
+                         want.values[want.rowPtr[r0]:want.rowPtr[r1]], r1 - r0, m)
+        assert_parity(blk, sub, what=f"block of shard {s}")
+    job.close()
+    g.close()
+
+
+def test_sharded_spmm_rectangular_and_empty_blocks():
+    """A != B (rectangular) and more shards than rows with products: empty blocks and empty segments travel too."""
+    from helpers import random_csr
+    A = random_csr(37, 200, 0.05, 3, sorted_rows=False, signed=False)
+    B = random_csr(200, 5000, 0.01, 4, sorted_rows=False, signed=False)
+    want = po.omp_spmm(A, B)
+    for shards, tr in ((4, hs.XCHG_PEER), (7, hs.XCHG_HOST)):
+        g = hs.Group(shards, devices=[0] * shards, transport=tr)
+        job = hs.ShardedSpMM(g, to_hs(A), to_hs(B))
+        nnz, _ = job.step()
+        assert nnz == want.nnz
+        for s in (0, shards - 1):
+            assert_parity(job.result(s), want, what=f"rectangular, {shards} shards, shard {s}")
+        job.close()
+        g.close()
+
+
+@pytest.mark.parametrize("shards,transport", [(2, hs.XCHG_PEER), (3, hs.XCHG_HOST), (1, hs.XCHG_RCCL)])
+def test_sharded_rmcl_steps_match_the_oracle(shards, transport):
+    """hip_gpuRmclIter_sharded one iteration at a time: every step from the previous state is the oracle's step up to
+    counted threshold ties (assert_rmcl_step) -- prune before gather, offsets, exchange."""
+    m, seed = 20000, 31
+    Mt = _graph(m, seed)
+    g = hs.Group(shards, devices=[0] * shards, transport=transport)
+    Mg = to_hs(Mt)
+    cur = Mt
+    for k in range(3):
+        nxt = hs.gpuRmclIter_sharded(g, 1, Mg, to_hs(cur))
+        nxt_h = po.CSRHost(nxt.rowPtr, nxt.colInd, nxt.values, m, m)
+        ndiff, ties, _ = assert_rmcl_step(nxt_h, Mt, cur, what=f"{shards} shards over {hs.XCHG_NAMES[transport]}, iteration {k + 1}")
+        gl = np.diff(nxt.rowPtr)
+        rs = np.add.reduceat(nxt.values.astype(np.float64), nxt.rowPtr[:-1][gl > 0])
+        assert np.allclose(rs, 1.0, atol=1e-5)
+        cur = nxt_h
+    # several iterations inside one call give the same matrix as the single-device entry point (up to ties: the fixture
+    # graph of the reference has none)
+    g.close()
+
+
+def test_gpuRmclIter_dispatches_to_the_sharded_loop(monkeypatch):
+    """hip_gpuRmclIter itself goes multi-shard when asked (SPGEMM_RMCL_SHARDS: logical shards on the visible devices; with
+    more than one device visible it does so on its own): same result as the single-device loop on a tie-free input."""
+    import os
+    from helpers import DATA
+    Mt = po.load(os.path.join(DATA, "own_graph.snap"), isTrans=True, mode=1)
+    monkeypatch.delenv("SPGEMM_RMCL_SHARDS", raising=False)
+    monkeypatch.setenv("SPGEMM_RMCL_DEVICES", "1")
+    one = hs.gpuRmclIter(3, to_hs(Mt), to_hs(Mt))
+    monkeypatch.setenv("SPGEMM_RMCL_SHARDS", "3")
+    three = hs.gpuRmclIter(3, to_hs(Mt), to_hs(Mt))
+    a, b = po.CSRHost(one.rowPtr, one.colInd, one.values, Mt.rows, Mt.cols), po.CSRHost(three.rowPtr, three.colInd, three.values, Mt.rows, Mt.cols)
+    assert_parity(b, a, what="3 logical shards vs one device")
+
+
+def test_group_argument_errors():
+    with pytest.raises(hs.SpgemmError):
+        hs.Group(0)
+    with pytest.raises(hs.SpgemmError):
+        hs.Group(2, devices=[0, 99])
+    with pytest.raises(hs.SpgemmError):
+        hs.Group(2, devices=[0, 0], transport=hs.XCHG_RCCL)       # RCCL needs one device per shard
+    ident = hs.unique_id()
+    assert len(ident) == hs.UNIQUE_ID_BYTES
+    g = hs.Group.of_rank(1, 0, 0, ident)                          # the multi-process constructor with a world of one
+    assert (g.nranks, g.nlocal, g.transport) == (1, 1, hs.XCHG_RCCL)
+    A = synth_csr(3000, 5, 2)
+    job = hs.ShardedSpMM(g, to_hs(A))
+    nnz, _ = job.step()
+    assert_parity(job.result(0), po.omp_spmm(A, A), what="one rank through create_rank")
+    job.close()
+    g.close()
+
+
+def test_cpp_driver_runs_the_sharded_loop():
+    """The C++ mirror's nrmcl driver (reference flags, Same/Diffs against the CPU checker) with the R-MCL loop cut into
+    logical shards behind the one call it makes -- gpuRmclIter (nlibs/qrmcl.cc:149-152)."""
+    import os
+    import subprocess
+    from helpers import DATA, ROOT
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    exe = os.path.join(ROOT, "tests", "cpp", "nrmcl.x")
+    env = dict(os.environ, SPGEMM_RMCL_SHARDS="2")
+    out = subprocess.run([exe, "-i", os.path.join(DATA, "own_graph.snap"), "-m", "3", "-r", "GPU"], capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Same" in out.stdout and "Diffs" not in out.stdout
+    assert "time pass readSNAPFile" in out.stdout and "time pass gpuRmclIter" in out.stdout
