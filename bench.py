@@ -17,6 +17,14 @@ Workloads (SURVEY.md §8d generator, sparse_matrix_with_flops_amd/synth.py):
   synth_256k_16  262 144^2,  ~16 nnz/row, seed 42    (BASELINE.json configs[1])
   synth_1m_32    1 048 576^2, ~32 nnz/row, seed 44   (configs[3], the row-sharded multi-GPU case)
   web_google_surrogate  916 428^2, ~5.5 nnz/row, nnzC/P ~0.49 (configs[2] by shape; the real file is not available)
+  rmcl_500k      configs[4]: the R-MCL loop (expand Mgt*Mt + inflate/prune/normalise fused: hip_rmcl_expand_prune) on the
+                 500 000-node power-law graph (seed 45), 10 iterations per step, device-resident
+
+N > 1: one process per GPU.  With --backend nccl (default) the ranks form a group INSIDE libspgemm_hip.so
+(spgemm_hip_group_create_rank, RCCL loaded by the library; the id travels over torch.distributed) and the exchange is the
+library's grouped ncclSend/ncclRecv; if that group cannot be made the step falls back to the torch.distributed exchange
+of sparse_matrix_with_flops_amd/dist.py and says so in "transport".  --backend gloo rehearses the N>1 path on a box with
+fewer GPUs than ranks.
 """
 import argparse
 import json
@@ -39,6 +47,11 @@ WORKLOADS = {
     "web_google_surrogate": dict(m=916428, seed=46, gen="web",
                                  desc="web-Google-shaped surrogate 916428^2, ~5.5 nnz/row, nnzC/P~0.49, seed 46, C=A*A "
                                       "(surrogate; reference totals unpinned)"),
+    # BASELINE.json configs[4]: R-MCL, 10 iterations
+    "rmcl_500k": dict(m=500000, seed=45, base=2, gen="rmcl", iters=10,
+                      desc="R-MCL (expand Mgt*Mt + inflate/prune/normalise) on a 500000-node power-law graph, seed 45, "
+                           "10 iterations per step, device-resident"),
+    "rmcl_20k": dict(m=20000, seed=91, base=2, gen="rmcl", iters=3, desc="R-MCL, 20000 nodes, 3 iterations (smoke-sized)"),
 }
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -69,6 +82,20 @@ def algorithmic_bytes(kind, rows, nnzA, P, nnzC):
     return 12 * rows + 12 * nnzA + 4 * P
 
 
+def traffic_for(workload, kernel, path=None):
+    """PMC-derived HBM bytes per launch of `kernel` (profiles/collect.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes of
+    this same command), newest round first.  -> ({raw, fetch_x2}, source) or (None, None)."""
+    cands = [path] if path else [os.path.join(ROOT, "profiles", f"r{r:02d}_{workload}_traffic.json") for r in (3, 2, 1)]
+    for tj in cands:
+        if tj and os.path.exists(tj):
+            k = json.load(open(tj)).get("kernels", {}).get(kernel)
+            if k:
+                return ({"raw": k.get("hbm_bytes_raw"), "fetch_x2": k.get("hbm_bytes_fetch_x2")},
+                        f"{os.path.relpath(tj, ROOT)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, collected "
+                        "separately (not in this run)")
+    return None, None
+
+
 def self_launch(args):
     """--gpus N > 1 from a plain shell: start the ranks as a child torchrun (this process has made no GPU call)."""
     import socket
@@ -95,58 +122,173 @@ def self_launch(args):
     raise SystemExit(0)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="synth_1m_16", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-verify", action="store_true", help="skip the parity gate against the CPU oracle")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-host-api", action="store_true", help="skip the host-array entry point (hip_CSR_SpMM) timing")
-    ap.add_argument("--no-gather", action="store_true",
-                    help="N>1: leave C row-sharded (no allgatherv inside the timed step)")
-    ap.add_argument("--chunks", type=int, default=4, help="N>1: sub-blocks per rank whose exchange overlaps the next one's numeric phase")
-    ap.add_argument("--traffic-json", default=None, help="profiles/*.json with PMC-derived HBM bytes per kernel")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (one GPU per rank).  gloo: rehearsal of the N>1 path on a box with fewer GPUs "
-                         "than ranks (ranks share devices; transport over host memory; not a performance number)")
-    ap.add_argument("--time-all-kernels", action="store_true",
-                    help="keep the HIP events of every kernel inside the timed region (diagnostic; costs ~3 %% of a step)")
-    args = ap.parse_args()
-    os.environ.setdefault("OMP_NUM_THREADS", str(os.cpu_count() or 1))   # cpu_baseline: all host threads
+class Ctx:
+    """what every workload needs: ranks, the process group, barriers"""
 
-    world = int(os.environ.get("WORLD_SIZE", "0"))
-    if world == 0:
-        if args.gpus > 1:
-            self_launch(args)                            # never returns
-        world = 1
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-
-    import torch
-    import torch.distributed as dist
-    from sparse_matrix_with_flops_amd import synth
-    from sparse_matrix_with_flops_amd import hipspgemm as hs
-    from sparse_matrix_with_flops_amd.dist import DeviceCSR, HipEngine, ShardedSpGEMM
-
-    if not torch.cuda.is_available() or hs.device_count() < 1:
-        raise SystemExit("bench.py needs an MI355X: the HIP SpGEMM path has no CPU fallback")
-    if args.backend == "gloo":
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    def __init__(self, args):
+        world = int(os.environ.get("WORLD_SIZE", "0"))
+        if world == 0:
+            if args.gpus > 1:
+                self_launch(args)                            # never returns; before anything touches the GPU
+            world = 1
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.args = torch, dist, args
+        self.world = world
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        from sparse_matrix_with_flops_amd import hipspgemm as hs
+        self.hs = hs
+        if not torch.cuda.is_available() or hs.device_count() < 1:
+            raise SystemExit("bench.py needs an MI355X: the HIP SpGEMM path has no CPU fallback")
         if args.backend == "gloo":
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        if dist.get_world_size() != args.gpus:
-            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+            self.local_rank = self.local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(self.local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if args.backend == "gloo":
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))
+            if dist.get_world_size() != args.gpus:
+                raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
 
-    wl = WORKLOADS[args.workload]
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def reduce_max_sum(self, values):
+        """-> (max over ranks, sum over ranks) of a list of floats"""
+        if self.world == 1:
+            return list(values), list(values)
+        dev = "cuda" if self.args.backend == "nccl" else "cpu"
+        tt = self.torch.tensor(values, dtype=self.torch.float64, device=dev)
+        mx = tt.clone()
+        self.dist.all_reduce(mx, op=self.dist.ReduceOp.MAX)
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.SUM)
+        return [float(x) for x in mx.tolist()], [float(x) for x in tt.tolist()]
+
+    def all_ok(self, ok):
+        """True only if every rank says so"""
+        if self.world == 1:
+            return bool(ok)
+        mx, _ = self.reduce_max_sum([0.0 if ok else 1.0])
+        return mx[0] == 0.0
+
+    def broadcast_bytes(self, data, n):
+        """rank 0's `n` bytes to everyone"""
+        if self.world == 1:
+            return data
+        dev = "cuda" if self.args.backend == "nccl" else "cpu"
+        t = self.torch.tensor(list(data) if self.rank == 0 else [0] * n, dtype=self.torch.uint8, device=dev)
+        self.dist.broadcast(t, 0)
+        return bytes(t.cpu().tolist())
+
+    def finish(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the SpGEMM workloads
+# ----------------------------------------------------------------------------------------------------------------------
+class TorchRunner:
+    """N = 1 (one-shot hip_gpuSpMM through dist.HipEngine) and the torch.distributed exchange for N > 1"""
+
+    def __init__(self, ctx, host, chunks):
+        from sparse_matrix_with_flops_amd.dist import HipEngine, ShardedSpGEMM
+        self.ctx = ctx
+        self.engine = HipEngine(ctx.local_rank, handles=chunks)
+        self.engine.handle.selftest()
+        self.job = ShardedSpGEMM(self.engine, host, None, chunks=chunks)
+        self.P = self.job.total_flops
+        self.handles = self.engine.handles[:max(1, chunks)]
+        self.out = None
+        self.transport = None if ctx.world == 1 else (
+            "torch.distributed (%s): grouped isend/irecv pairs, sub-blocks overlapping the next one's numeric phase" % ctx.args.backend)
+
+    def step(self, gather):
+        self.out = None                                  # the consumer is done with the previous C: back to the allocator
+        self.out = self.job.step(gather)
+
+    def device_ms(self):
+        return sum(h.stats()["ms_total"] for h in self.handles)
+
+    def local_nnz(self):
+        from sparse_matrix_with_flops_amd.dist import DeviceCSR
+        return self.out.nnz if isinstance(self.out, DeviceCSR) else int(self.out[1].numel())
+
+    def result_host(self):
+        from sparse_matrix_with_flops_amd.dist import DeviceCSR
+        if isinstance(self.out, DeviceCSR):
+            return self.out.to_host()
+        return tuple(x.cpu().numpy() for x in self.out)
+
+    def local_rows(self):
+        return self.job.r0, self.job.r1
+
+    def local_row_flops(self):
+        return self.engine.row_flops(self.job.A_local, self.job.B), self.job.A_local["rowPtr"].cpu().numpy().astype(np.int64)
+
+    def release(self):
+        self.out = None
+
+
+class GroupRunner:
+    """N > 1 behind the C ABI: one-shard group per process (spgemm_hip_group_create_rank), RCCL inside the library"""
+
+    def __init__(self, ctx, host):
+        hs = ctx.hs
+        rp, ci, v, m, _ = host
+        ident = ctx.broadcast_bytes(hs.unique_id() if ctx.rank == 0 else b"", hs.UNIQUE_ID_BYTES)
+        self.group = hs.Group.of_rank(ctx.world, ctx.rank, ctx.local_rank, ident)
+        self.hA = hs.CSR.from_arrays(rp, ci, v, m, m)
+        self.job = hs.ShardedSpMM(self.group, self.hA)
+        self.handles = [self.job.handle(0)]
+        self.handles[0].selftest()
+        self.ctx = ctx
+        self.P = None
+        self.nnz = 0
+        self.transport = "rccl inside libspgemm_hip.so (spgemm_hip_group_create_rank): grouped ncclSend/ncclRecv per peer"
+
+    def step(self, gather):
+        self.nnz, self.P = self.job.step(gather)
+
+    def device_ms(self):
+        return self.job.info()["ms_compute"]
+
+    def local_nnz(self):
+        return int(self.nnz)
+
+    def result_host(self):
+        c = self.job.result(0)
+        return c.rowPtr, c.colInd, c.values
+
+    def local_rows(self):
+        e = self.job.info()["ends"]
+        return e[self.ctx.rank], e[self.ctx.rank + 1]
+
+    def local_row_flops(self):
+        r0, r1 = self.local_rows()
+        rp = self.hA.rowPtr.astype(np.int64)
+        deg = np.diff(rp)
+        cols = self.hA.colInd[rp[r0]:rp[r1]]
+        f = np.zeros(r1 - r0, dtype=np.int64)
+        np.add.at(f, np.repeat(np.arange(r1 - r0), deg[r0:r1]), deg[cols])
+        return f, rp[r0:r1 + 1] - rp[r0]
+
+    def release(self):
+        pass
+
+
+def bench_spgemm(ctx, args, wl):
+    from sparse_matrix_with_flops_amd import synth
+    hs, world, rank = ctx.hs, ctx.world, ctx.rank
     t0 = time.time()
     if wl.get("gen") == "web":
         rp, ci, v = synth.webgraph_csr(wl["m"], wl["seed"])
@@ -154,35 +296,38 @@ def main():
         rp, ci, v = synth.powerlaw_csr(wl["m"], wl["seed"], wl["base"])
     m = wl["m"]
     gen_s = time.time() - t0
+    host = (rp, ci, v, m, m)
     chunks = max(1, args.chunks) if world > 1 else 1
-    engine = HipEngine(local_rank, handles=chunks)
-    engine.handle.selftest()
-    job = ShardedSpGEMM(engine, (rp, ci, v, m, m), None, chunks=chunks)
-    P = job.total_flops
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+    runner, fallback = None, None
+    # BENCH_FORCE_GROUP=1: rehearsal of the N>1 plumbing on one GPU (a group of ONE rank: its segment makes the round trip
+    # through the library's RCCL transport to itself)
+    if (world > 1 and args.backend == "nccl" and not args.torch_exchange) or os.environ.get("BENCH_FORCE_GROUP"):
+        try:
+            runner = GroupRunner(ctx, host)
+        except Exception as e:                                            # noqa: BLE001 -- any failure: the other transport
+            fallback = f"{type(e).__name__}: {e}"
+            runner = None
+        if not ctx.all_ok(runner is not None):
+            runner = None
+            fallback = fallback or "another rank could not create its group"
+    if runner is None:
+        runner = TorchRunner(ctx, host, chunks)
 
     def set_timing(mask):
-        for hnd in engine.handles:
+        for hnd in runner.handles:
             hnd.set_kernel_timing(mask)
 
     gather = not args.no_gather
-    out = None
-    for _ in range(args.warmup):
-        out = None                                     # the consumer is done with the previous C: its arrays go back
-        out = job.step(gather)                         # to the caching allocator and the next step reuses them
+    for _ in range(max(1, args.warmup)):
+        runner.step(gather)
+    P = runner.P
 
     # ---- untimed profiling pass: every kernel bracketed by HIP events -> per-kernel averages, dominant kernel
     set_timing(ALL_KERNELS)
     prof_ms, nprof = {}, 3
     for _ in range(nprof):
-        out = None
-        out = job.step(gather)
-        for hnd in engine.handles:
+        runner.step(gather)
+        for hnd in runner.handles:
             for kname, ms in hnd.stats()["ms_kernel"].items():
                 prof_ms[kname] = prof_ms.get(kname, 0.0) + ms
     prof_avg = {k_: v_ / nprof for k_, v_ in prof_ms.items()}
@@ -194,38 +339,26 @@ def main():
     # ---- timed region
     kern_ms = {}
     phase_ms = {"ms_classify": 0.0, "ms_symbolic": 0.0, "ms_scan_alloc": 0.0, "ms_numeric": 0.0, "ms_total": 0.0}
-    barrier()
+    ctx.barrier()
     t0 = time.perf_counter()
     dev_ms = 0.0
     for _ in range(args.steps):
-        out = None
-        out = job.step(gather)
-        for hnd in engine.handles[:chunks]:
+        runner.step(gather)
+        dev_ms += runner.device_ms()
+        for hnd in runner.handles:
             st = hnd.stats()                           # HIP-event durations of this step's launches (handle's stream)
-            dev_ms += st["ms_total"]
             for kname, ms in st["ms_kernel"].items():
                 kern_ms[kname] = kern_ms.get(kname, 0.0) + ms
             for kk in phase_ms:
                 phase_ms[kk] += st[kk]
-    barrier()
+    ctx.barrier()
     elapsed = time.perf_counter() - t0
     set_timing(0)
 
-    if isinstance(out, DeviceCSR):
-        nnz_local = out.nnz
-    else:
-        nnz_local = int(out[1].numel())
-    nnz_sum = nnz_local
-    if world > 1:
-        tt = torch.tensor([elapsed, dev_ms, float(nnz_local)], dtype=torch.float64,
-                          device=("cuda" if args.backend == "nccl" else "cpu"))
-        mx = tt.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        elapsed, dev_ms = float(mx[0].item()), float(mx[1].item())
-        nnz_sum = int(tt[2].item())
+    nnz_local = runner.local_nnz()
+    (elapsed, dev_ms, _), (_, _, nnz_sum) = ctx.reduce_max_sum([elapsed, dev_ms, float(nnz_local)])
     ms_per_step = elapsed * 1e3 / args.steps
-    nnzC = nnz_local if (world == 1 or gather) else nnz_sum
+    nnzC = nnz_local if (world == 1 or gather) else int(nnz_sum)
     nnzA = int(rp[-1])
     bytes_alg = synth.bytes_alg(m, nnzA, P, nnzC)
     gflops = 2.0 * P / (ms_per_step * 1e-3) / 1e9
@@ -238,30 +371,25 @@ def main():
         "config": {"workload": wl["desc"], "name": args.workload, "m": m, "nnzA": nnzA, "intermediate_nnz_P": P,
                    "nnzC": nnzC, "bytes_alg": bytes_alg,
                    "parallelism": ("single GPU" if world == 1 else f"A row-sharded by flops over {world} GPUs, B replicated, "
-                                   f"allgatherv of C (send/recv pairs over xGMI) in {chunks} sub-blocks per rank, each "
-                                   "overlapping the next one's numeric phase")},
-        "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": (args.backend if world > 1 else None),
+                                   "allgatherv of C's row segments over xGMI")},
+        "rccl_ranks": (ctx.dist.get_world_size() if world > 1 else 1), "backend": (args.backend if world > 1 else None),
+        "transport": runner.transport, "transport_fallback_reason": fallback,
         "output_nnz_per_s": round(nnzC / (ms_per_step * 1e-3), 1),
         # device time of the SpGEMM phases alone (max over ranks, HIP events): what the step costs without the allgatherv of C
         "compute_only": {"ms_per_step": round(dev_ms / args.steps, 4),
                          "value": round(2.0 * P / max(dev_ms / args.steps * 1e-3, 1e-12) / 1e9, 3), "unit": "GFLOP/s"},
-        "gather_in_step": bool(world > 1 and gather),
+        "gather_in_step": bool((world > 1 or isinstance(runner, GroupRunner)) and gather),
         "pipeline_bytes_alg_GBs": round(bytes_alg / (ms_per_step * 1e-3) / 1e9, 2),
         "pipeline_frac_of_hbm_peak": round(bytes_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world, 4),
     }
 
     if rank == 0:
         # ---- C of the last step on the host (parity gate; per-bin counts for the roofline)
-        if isinstance(out, DeviceCSR):
-            rpc, jc_h, cv_h = out.to_host()
-        else:
-            rpc, jc_h, cv_h = (x.cpu().numpy() for x in out)
+        rpc, jc_h, cv_h = runner.result_host()
         rpc = rpc.astype(np.int64)
-
-        # ---- roofline of the dominant kernel (rank 0's local rows; duration from HIP events INSIDE the timed region)
-        flops_rows = engine.row_flops(job.A_local, job.B)
-        rpl = job.A_local["rowPtr"].cpu().numpy().astype(np.int64)
-        cnt_rows = np.diff(rpc[job.r0:job.r1 + 1]) if (world > 1 and gather) else np.diff(rpc)
+        r0, r1 = runner.local_rows()
+        flops_rows, rpl = runner.local_row_flops()
+        cnt_rows = np.diff(rpc[r0:r1 + 1]) if (world > 1 and gather) else np.diff(rpc)
         b = bin_of(flops_rows)
         per_bin = {}
         for q in range(9):
@@ -277,20 +405,22 @@ def main():
             nzc_ = sum(per_bin[q][3] for q in bins)
             ab = algorithmic_bytes(kind, rows_, nza_, p_, nzc_)
             ach = ab / (avg_dom * 1e-3) / 1e9
-            traffic, tsrc = None, None
-            tj = args.traffic_json or os.path.join(ROOT, "profiles", f"r02_{args.workload}_traffic.json")
-            if os.path.exists(tj):      # PMC-derived HBM bytes per launch, collected by profiles/collect.sh (separate passes)
-                traffic = json.load(open(tj)).get("kernels", {}).get(dom, {}).get("hbm_bytes_raw")
-                tsrc = (f"{os.path.relpath(tj, ROOT)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, collected "
-                        "separately (not in this run)")
+            tr, tsrc = traffic_for(args.workload, dom, args.traffic_json)
             roof = {"bound": "hbm", "kernel": dom, "avg_launch_ms": round(avg_dom, 4), "alg_bytes_per_launch": ab,
                     "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "traffic_source": tsrc,
+                    # traffic: FETCH_SIZE corrected x2 as the guide prescribes for gfx950 (every fabric read request of these
+                    # kernels is a 128-byte one: profiles/*tcc_counters*); the raw figure beside it
+                    "traffic": (tr or {}).get("fetch_x2"), "traffic_raw": (tr or {}).get("raw"),
+                    "traffic_fetch_x2": (tr or {}).get("fetch_x2"),
+                    "traffic_over_alg": (round(tr["fetch_x2"] / ab, 3) if tr and tr.get("fetch_x2") else None),
+                    "traffic_source": tsrc,
                     "rows": rows_, "products": p_, "nnzC": nzc_,
                     "timing": "dominant kernel: HIP events on the handle's stream inside the timed region; all_kernels_avg_ms: "
                               f"a separate untimed pass of {nprof} steps with every kernel bracketed",
                     "all_kernels_avg_ms": {k_: round(v_, 4) for k_, v_ in sorted(prof_avg.items(), key=lambda kv: -kv[1])},
-                    "phases_avg_ms": {k_: round(v_ / args.steps, 4) for k_, v_ in phase_ms.items()}}
+                    "phases_avg_ms": {k_: round(v_ / args.steps, 4) for k_, v_ in phase_ms.items()},
+                    "per_bin": {str(q): {"rows": per_bin[q][0], "nnzA": per_bin[q][1], "P": per_bin[q][2], "nnzC": per_bin[q][3]}
+                                for q in range(9)}}
         result["roofline"] = roof
 
         # ---- parity gate (every N) + CPU baseline (N=1 only); the oracle is the checker, never the thing measured above
@@ -319,7 +449,7 @@ def main():
         if world == 1 and not args.no_host_api:
             # the drop-in a reference caller of CSR::*spmm gets (nlibs/CSR.cc:122-134): host arrays in, malloc()ed host
             # arrays out.  PCIe-inclusive, never `value`.
-            out = None
+            runner.release()
             hA = hs.CSR.from_arrays(rp, ci, v, m, m)
             runs = hs.host_api_timed(hA, hA, reps=3)
             best = min(runs[1:], key=lambda r_: r_["ms_total"])          # first run: pinned slots are allocated
@@ -346,10 +476,194 @@ def main():
                 raise SystemExit("parity gate failed")
         result["setup"] = {"generate_s": round(gen_s, 2), "host_cpus": os.cpu_count()}
         print(json.dumps(result))
-    out = None
+    runner.release()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: the R-MCL loop
+# ----------------------------------------------------------------------------------------------------------------------
+def bench_rmcl(ctx, args, wl):
+    """A step = `iters` iterations of Mt <- prune(Mgt * Mt) from the initial Mt, device-resident (hip_rmcl_expand_prune per
+    iteration: the product is never materialised).  value = 2 * (sum of the iterations' products) / t.
+    N > 1: hip_gpuRmclIter_sharded over the library's group (host arrays in and out: the copies are inside the step)."""
+    from oracle import pyoracle as po                       # graph construction (rmclInit restatement) + checker/baseline only
+    from sparse_matrix_with_flops_amd import synth
+    hs, world, rank = ctx.hs, ctx.world, ctx.rank
+    m, iters = wl["m"], wl["iters"]
+    t0 = time.time()
+    rp, ci, v = synth.powerlaw_csr(m, wl["seed"], wl["base"])
+    ri = np.repeat(np.arange(m, dtype=np.int32), np.diff(rp))
+    Mt = po.rmcl_init(m, m, ci, ri, np.ones_like(v))        # transpose + self loops + 1/deg (nlibs/qrmcl.cc:126-134)
+    gen_s = time.time() - t0
+    H = hs.CSR.from_arrays(Mt.rowPtr, Mt.colInd, Mt.values, m, m)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_large.json"))).get(f"rmcl_{m}_{wl['seed']}")
+
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        ident = ctx.broadcast_bytes(hs.unique_id() if rank == 0 else b"", hs.UNIQUE_ID_BYTES)
+        grp = hs.Group.of_rank(world, rank, ctx.local_rank, ident)
+        for _ in range(max(1, args.warmup)):
+            R = hs.gpuRmclIter_sharded(grp, iters, H, H)
+        ctx.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            R = hs.gpuRmclIter_sharded(grp, iters, H, H)
+        ctx.barrier()
+        (elapsed,), _ = ctx.reduce_max_sum([time.perf_counter() - t0])
+        if rank == 0:
+            # products per iteration: the reference-made summary holds nnz of the raw products, not P; the 1-GPU run reports P
+            ms = elapsed * 1e3 / args.steps
+            print(json.dumps({
+                "metric": "R-MCL loop wall time (host arrays in/out)", "value": round(ms, 3), "unit": "ms", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": False,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": wl["desc"], "name": args.workload, "m": m, "iterations": iters,
+                           "parallelism": f"Mgt row-sharded by flops over {world} GPUs, Mt replicated, pruned blocks gathered "
+                                          "every iteration (hip_gpuRmclIter_sharded; host arrays in/out inside the step)"},
+                "final_nnz": int(R.nnz), "golden_final_nnz": (gold["per_iter"][iters - 1]["nnz"] if gold else None)}))
+        grp.close()
+        return
+
+    h = hs.Handle(0)
+    h.selftest()
+    G_ = H.toGpuCSR()
+
+    def loop(cur, collect):
+        per = []
+        for _ in range(iters):
+            i_, j_, c_, nn = hs.rmcl_expand_prune_raw(h, G_.rowPtr, G_.colInd, G_.values, G_.nnz, cur.rowPtr, cur.colInd,
+                                                      cur.values, cur.nnz, m, m, m)
+            st = h.stats()
+            if collect:
+                per.append({"P": st["total_flops"], "nnz_in": cur.nnz, "kept": nn, "ms": st["ms_total"],
+                            "ms_kernel": st["ms_kernel"]})
+            else:
+                per.append(st["ms_total"])
+            cur.deviceDispose()
+            cur = hs.CSR(c_, j_, i_, m, m, nn, True)
+        return cur, per
+
+    # the loop starts from a fresh device copy of Mt every step; that upload is setup and stays outside the timing
+    nruns = max(1, args.warmup) + 1 + args.steps
+    starts = [H.toGpuCSR() for _ in range(nruns)]
+    for _ in range(max(1, args.warmup)):
+        fin, _ = loop(starts.pop(), False)
+        fin.deviceDispose()
+    h.set_kernel_timing(ALL_KERNELS)
+    fin, per = loop(starts.pop(), True)                     # profiling pass: per-iteration products, kept entries, kernels
+    fin.deviceDispose()
+    h.set_kernel_timing(0)
+    P_total = sum(p_["P"] for p_ in per)
+    ctx.barrier()
+    t0 = time.perf_counter()
+    dev_ms = 0.0
+    last = None
+    for _ in range(args.steps):
+        if last is not None:
+            last.deviceDispose()
+        last, ms_list = loop(starts.pop(), False)
+        dev_ms += sum(ms_list)
+    ctx.barrier()
+    elapsed = time.perf_counter() - t0
+    ms_per_step = elapsed * 1e3 / args.steps
+    final = last.toCpuCSR()
+    last.deviceDispose()
+    G_.deviceDispose()
+
+    # algorithmic bytes of one fused iteration: read A (= Mgt) and the gathered B entries, write only what survives the prune
+    nnzA = int(Mt.nnz)
+    it_bytes = [8 * (m + 1) + 16 * nnzA + 8 * p_["P"] + 8 * p_["kept"] for p_ in per]
+    kern_tot = {}
+    for p_ in per:
+        for k_, ms in p_["ms_kernel"].items():
+            kern_tot[k_] = kern_tot.get(k_, 0.0) + ms
+    cand = {k_: v_ for k_, v_ in kern_tot.items() if k_.startswith("k_num")}
+    dom = max(cand, key=cand.get) if cand else None
+    peak_it = max(range(iters), key=lambda i: per[i]["P"])
+    result = {
+        "metric": "SpGEMM GFLOP/s (2*intermediate_nnz/sec), R-MCL loop (expand + prune fused)",
+        "value": round(2.0 * P_total / (ms_per_step * 1e-3) / 1e9, 3), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl["desc"], "name": args.workload, "m": m, "nnz_Mt0": nnzA, "iterations": iters,
+                   "products_per_step": P_total, "parallelism": "single GPU"},
+        "compute_only": {"ms_per_step": round(dev_ms / args.steps, 3)},
+        "per_iteration": [{"P": p_["P"], "nnz_in": p_["nnz_in"], "kept": p_["kept"], "ms": round(p_["ms"], 3),
+                           "alg_GBs": round(b_ / (p_["ms"] * 1e-3) / 1e9, 1)} for p_, b_ in zip(per, it_bytes)],
+        "pipeline_bytes_alg_GBs": round(sum(it_bytes) / (ms_per_step * 1e-3) / 1e9, 2),
+        "pipeline_frac_of_hbm_peak": round(sum(it_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "roofline": {"bound": "hbm",
+                     "kernel": f"hip_rmcl_expand_prune, iteration {peak_it + 1} (largest product); dominant numeric kernel of the loop: {dom}",
+                     "avg_launch_ms": round(per[peak_it]["ms"], 4), "alg_bytes_per_launch": it_bytes[peak_it],
+                     "achieved": round(it_bytes[peak_it] / (per[peak_it]["ms"] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(it_bytes[peak_it] / (per[peak_it]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "traffic": None,
+                     "alg_bytes": "8(m+1) + 16 nnz(Mgt) + 8 P + 8 kept: the product is never written, only what survives the prune",
+                     "loop_kernels_ms": {k_: round(v_, 3) for k_, v_ in sorted(kern_tot.items(), key=lambda kv: -kv[1])}},
+    }
+    if not args.no_verify:
+        rs = np.add.reduceat(final.values.astype(np.float64), final.rowPtr[:-1][np.diff(final.rowPtr) > 0])
+        ok = bool(np.allclose(rs, 1.0, atol=1e-5))
+        if gold and iters <= len(gold["per_iter"]):                        # reference-made per-iteration summary
+            g_last = gold["per_iter"][iters - 1]
+            ok = ok and abs(int(final.nnz) - g_last["nnz"]) <= 5e-4 * g_last["nnz"] + 4096
+            result["golden"] = {"final_nnz": int(final.nnz), "reference_final_nnz": g_last["nnz"],
+                                "source": "tests/golden/golden_large.json (reference-pinned kernels, cross-checked against RMCL(file, 10, OMP))"}
+        result["parity"] = (f"ok (rows sum to 1; nnz after {iters} iterations within the threshold-tie drift of the reference "
+                            "summary; step-by-step parity: tests/test_gpu_rmcl.py)") if ok else "FAILED"
+        if not ok:
+            print(json.dumps(result))
+            raise SystemExit("parity gate failed")
+    if not args.no_cpu_baseline:
+        if po.have_ref():                                                  # the reference's own multi-threaded loop, 2 iterations
+            sample_it = min(2, iters)
+            _, dt = po.ref_mt_rmcl(Mt, Mt, sample_it, opt=1)
+            Ps = sum(p_["P"] for p_ in per[:sample_it])
+            threads = po.ref().ref_max_threads()
+            result["cpu_baseline"] = {"value": round(2.0 * Ps / dt / 1e9, 4), "unit": "GFLOP/s", "cores": int(threads), "kind": "reference",
+                                      "sample": f"mtRmclIter(OMP, stride 512) of the reference (oracle/_ref) on the first {sample_it} "
+                                                f"iterations of the same graph ({Ps} products), {dt * 1e3:.0f} ms", "ms": round(dt * 1e3, 1)}
+        else:
+            t1 = time.perf_counter()
+            po.rmcl_iters(Mt, Mt, 1)
+            dt = time.perf_counter() - t1
+            result["cpu_baseline"] = {"value": round(2.0 * per[0]["P"] / dt / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+                                      "sample": f"seqRmclIter restatement, first iteration only ({per[0]['P']} products), {dt * 1e3:.0f} ms",
+                                      "ms": round(dt * 1e3, 1)}
+    result["setup"] = {"generate_s": round(gen_s, 2), "host_cpus": os.cpu_count()}
+    print(json.dumps(result))
+    h.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="synth_1m_16", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-verify", action="store_true", help="skip the parity gate against the CPU oracle")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the host-array entry point (hip_CSR_SpMM) timing")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="N>1: leave C row-sharded (no allgatherv inside the timed step)")
+    ap.add_argument("--chunks", type=int, default=4,
+                    help="N>1, torch.distributed exchange: sub-blocks per rank whose exchange overlaps the next one's numeric phase")
+    ap.add_argument("--torch-exchange", action="store_true",
+                    help="N>1: exchange through torch.distributed (dist.py) instead of the library's own RCCL group")
+    ap.add_argument("--traffic-json", default=None, help="profiles/*.json with PMC-derived HBM bytes per kernel")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (one GPU per rank).  gloo: rehearsal of the N>1 path on a box with fewer GPUs "
+                         "than ranks (ranks share devices; transport over host memory; not a performance number)")
+    ap.add_argument("--time-all-kernels", action="store_true",
+                    help="keep the HIP events of every kernel inside the timed region (diagnostic; costs ~3 %% of a step)")
+    args = ap.parse_args()
+    os.environ.setdefault("OMP_NUM_THREADS", str(os.cpu_count() or 1))   # cpu_baseline: all host threads
+    ctx = Ctx(args)
+    wl = WORKLOADS[args.workload]
+    if wl.get("gen") == "rmcl":
+        bench_rmcl(ctx, args, wl)
+    else:
+        bench_spgemm(ctx, args, wl)
+    ctx.finish()
 
 
 if __name__ == "__main__":

@@ -244,6 +244,8 @@ int hip_sharded_spmm_create(spgemm_group* g, const int* IA, const int* JA, const
 int hip_sharded_spmm_step(spgemm_sharded* job, int gather, long long* nnzC, long long* totalP);
 int hip_sharded_spmm_result(spgemm_sharded* job, int local_shard, int** IC, int** JC, float** C, int* nnzC, int* rows);
 int hip_sharded_spmm_info(spgemm_sharded* job, int* ends, float* ms_compute, float* ms_exchange);
+/* the handle a local shard computes with (spgemm_hip_get_stats / spgemm_hip_set_kernel_timing); owned by the group */
+spgemm_handle* hip_sharded_spmm_handle(spgemm_sharded* job, int local_shard);
 int hip_sharded_spmm_destroy(spgemm_sharded* job);
 
 /* gpuRmclIter over a group: Mgt's row blocks (cut by the flops of the first expansion) stay resident per shard, Mt is

@@ -281,6 +281,22 @@ def ref_rmcl(path, iters, opt=0):
     return _load_common(ref().ref_rmcl, ref().ref_free, path, C.c_int(iters), C.c_int(opt))
 
 
+def ref_mt_rmcl(Mgt, Mt, iters, opt=1, stride=512):
+    """The reference's multi-threaded R-MCL loop, mtRmclIter (nlibs/qrmcl.cc:8-84), on in-memory CSRs; opt: 1 OMP, 4 SOMP
+    (enum RunOptions).  -> (new Mt, seconds spent inside the reference's loop)."""
+    L = ref()
+    L.ref_mt_rmcl_iter.restype = C.c_double
+    rows, cols, nnz = C.c_int(), C.c_int(), C.c_int()
+    rp, ci, v = _I(), _I(), _F()
+    dt = L.ref_mt_rmcl_iter(C.c_int(iters), C.c_int(opt), C.c_int(stride), C.c_int(Mgt.rows), C.c_int(Mgt.cols),
+                            _ip(Mgt.rowPtr), _ip(Mgt.colInd), _fp(Mgt.values), C.c_int(Mgt.nnz),
+                            _ip(Mt.rowPtr), _ip(Mt.colInd), _fp(Mt.values), C.c_int(Mt.nnz),
+                            C.byref(rows), C.byref(cols), C.byref(nnz), C.byref(rp), C.byref(ci), C.byref(v))
+    out = CSRHost(_take(rp, rows.value + 1, np.int32, L.ref_free), _take(ci, nnz.value, np.int32, L.ref_free),
+                  _take(v, nnz.value, np.float32, L.ref_free), rows.value, cols.value)
+    return out, float(dt)
+
+
 def read_snap(path, isTrans=False):
     """-> (rows, cols, ri, ci, v) raw triplets; oracle_read_snap == COO::readSNAPFile."""
     L = lib()

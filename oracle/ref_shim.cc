@@ -20,6 +20,7 @@
 //   dynamic_omp_CSR_IC_nnzC_footprints / arrayEqualPartition   nlibs/static_omp_csr_kernel.cc:28-95, tools/util.cc:109-121
 //   COO::readSNAPFile/orderedAndDuplicatesRemoving/toCSR  nlibs/COO.cc:48-291
 //   rmclInit / RMCL            nlibs/qrmcl.cc:126-164
+//   mtRmclIter                 nlibs/qrmcl.cc:8-84   (the multi-threaded loop on in-memory CSRs: bench.py's R-MCL cpu_baseline)
 //   CSR::makeOrdered / isEqual nlibs/CSR.cc:73-86, nlibs/CSR.h:195-245
 #include <omp.h>
 #include <stdlib.h>
@@ -34,6 +35,8 @@
 void group_CSR_flops(const int IA[], const int JA[], const int IB[], const int JB[],
                      const int m, const int n, int* IC, int& nnzC, int* rowFlops,
                      int* groups, int* tops, const int stride);
+
+void mtRmclIter(const int maxIter, const CSR Mgt, CSR& Mt, const int stride, const RunOptions runOptions);   // nlibs/qrmcl.cc:8
 
 extern "C" {
 
@@ -113,6 +116,23 @@ int ref_rmcl(const char* fname, int maxIters, int runOption,
   CSR mt = RMCL(fname, maxIters, (RunOptions)runOption);
   csr_out(mt, rows, cols, nnz, rp, ci, v);
   return 0;
+}
+
+// mtRmclIter(maxIter, Mgt, Mt, stride, runOption) on CSRs that are already in memory (no file parsing inside the timed
+// call).  Mt is replaced in place by the reference (old arrays disposed, new ones malloc()ed), so both operands are deep
+// copies of the caller's arrays.  Returns the seconds spent inside mtRmclIter; the result comes back like ref_rmcl's.
+double ref_mt_rmcl_iter(int maxIters, int runOption, int stride, int rows, int cols,
+                        const int* gI, const int* gJ, const float* gV, int gnnz,
+                        const int* tI, const int* tJ, const float* tV, int tnnz,
+                        int* orows, int* ocols, int* onnz, int** rp, int** ci, float** v) {
+  CSR g((QValue*)gV, (int*)gJ, (int*)gI, rows, cols, gnnz), t((QValue*)tV, (int*)tJ, (int*)tI, rows, cols, tnnz);
+  CSR Mgt = g.deepCopy(), Mt = t.deepCopy();
+  const double t0 = omp_get_wtime();
+  mtRmclIter(maxIters, Mgt, Mt, stride, (RunOptions)runOption);
+  const double dt = omp_get_wtime() - t0;
+  Mgt.dispose();
+  csr_out(Mt, orows, ocols, onnz, rp, ci, v);
+  return dt;
 }
 
 void ref_make_ordered(int rows, int cols, int nnz, int* rp, int* ci, float* v) {

@@ -52,7 +52,7 @@ RcclApi& rccl() {
     const char* cand[] = {env, "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"};
     for (const char* c : cand) {
       if (!c || !c[0]) continue;
-      api.so = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+      api.so = dlopen(c, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);   // DEEPBIND: its own symbols before another loaded RCCL's
       if (api.so) break;
       api.why = dlerror();
     }
@@ -597,6 +597,12 @@ extern "C" int hip_sharded_spmm_result(spgemm_sharded* job, int local_shard, int
   *IC = hI; *JC = hJ; *C = hV; *nnzC = (int)nz;
   if (rows) *rows = nr;
   return SPGEMM_OK;
+}
+
+// the handle local shard `local_shard` computes with (per-call statistics, per-kernel timing); owned by the group
+extern "C" spgemm_handle* hip_sharded_spmm_handle(spgemm_sharded* job, int local_shard) {
+  if (!job || local_shard < 0 || local_shard >= (int)job->loc.size()) return nullptr;
+  return job->g->sh[(size_t)local_shard].h;
 }
 
 extern "C" int hip_sharded_spmm_info(spgemm_sharded* job, int* ends, float* ms_compute, float* ms_exchange) {

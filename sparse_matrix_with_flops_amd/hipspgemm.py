@@ -39,6 +39,7 @@ EXPORTS = [
     "spgemm_hip_group_create", "spgemm_hip_unique_id", "spgemm_hip_group_create_rank", "spgemm_hip_group_info",
     "spgemm_hip_group_destroy", "hip_sharded_spmm_create", "hip_sharded_spmm_step", "hip_sharded_spmm_result",
     "hip_sharded_spmm_info", "hip_sharded_spmm_destroy", "hip_gpuRmclIter_sharded", "spgemm_hip_host_api_stats",
+    "hip_sharded_spmm_handle",
 ]
 XCHG_AUTO, XCHG_RCCL, XCHG_PEER, XCHG_HOST = 0, 1, 2, 3
 XCHG_NAMES = {0: "auto", 1: "rccl", 2: "peer", 3: "host"}
@@ -143,6 +144,8 @@ def lib():
         L.hip_sharded_spmm_result.argtypes = [C.c_void_p, C.c_int, C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I, _I]
         L.hip_sharded_spmm_info.argtypes = [C.c_void_p, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.hip_sharded_spmm_destroy.argtypes = [C.c_void_p]
+        L.hip_sharded_spmm_handle.argtypes = [C.c_void_p, C.c_int]
+        L.hip_sharded_spmm_handle.restype = C.c_void_p
         L.hip_gpuRmclIter_sharded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + host_in + host_in + \
             [C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I]
         L.free = C.CDLL(None).free
@@ -169,9 +172,13 @@ def device_count():
 class Handle:
     """spgemm_handle: one HIP stream + workspace on one device."""
 
-    def __init__(self, device=0):
-        self._h = C.c_void_p()
-        _check(lib().spgemm_hip_create(C.byref(self._h), int(device)), "spgemm_hip_create")
+    def __init__(self, device=0, _borrowed=None):
+        self._own = _borrowed is None
+        if _borrowed is not None:                   # a handle owned by someone else (a group's shard): never destroyed here
+            self._h = C.c_void_p(_borrowed)
+        else:
+            self._h = C.c_void_p()
+            _check(lib().spgemm_hip_create(C.byref(self._h), int(device)), "spgemm_hip_create")
         self.device = device
 
     @property
@@ -194,9 +201,9 @@ class Handle:
         _check(lib().spgemm_hip_set_kernel_timing(self._h, int(mask) & 0xFFFFFFFF), "spgemm_hip_set_kernel_timing")
 
     def close(self):
-        if self._h:
+        if self._h and self._own:
             lib().spgemm_hip_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -617,6 +624,13 @@ class ShardedSpMM:
                                          C.byref(rows)), "hip_sharded_spmm_result")
         rp, ci, v = _take_malloced(L, pi, pj, pv, rows.value, n.value)
         return CSR(v, ci, rp, rows.value, self.n, n.value)
+
+    def handle(self, local_shard=0):
+        """the spgemm_handle of a local shard as a (non-owning) Handle: stats(), set_kernel_timing()"""
+        p = lib().hip_sharded_spmm_handle(self._j, int(local_shard))
+        if not p:
+            raise SpgemmError("no such local shard")
+        return Handle(_borrowed=p)
 
     def info(self):
         ends = (C.c_int * (self.group.nranks + 1))()

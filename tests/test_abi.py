@@ -20,7 +20,7 @@ def _built():
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "spgemm_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"\b(?:int|void\*?|const char\*)\s+\*?\s*((?:spgemm_hip|hip)_\w+)\s*\(", text)
+    names = re.findall(r"\b(?:int|void\*?|const char\*|spgemm_handle\*)\s+\*?\s*((?:spgemm_hip|hip)_\w+)\s*\(", text)
     return sorted(set(names))
 
 

@@ -177,6 +177,38 @@ def test_config3_1m_rows_32_per_row_vs_reference_summary(handle):
     assert [int(x) for x in equal_partition64(prefix, 8)] == g["partition8"]
 
 
+def test_config2_web_google_surrogate_full_parity(handle):
+    """BASELINE configs[2] by SHAPE (the real web-Google file is in neither container: "surrogate; reference totals
+    unpinned"): synth.webgraph_csr -- 916 428 rows, ~5.5 entries per row, skewed in- and out-degree, nnz(C)/P = 0.49, the
+    compressive regime of real web graphs that the power-law workloads (nnz(C)/P >= 0.91) never enter: about every second
+    product meets a column that is already in its row's table.  Full size, full parity (rowPtr, sorted colInd bit-exact,
+    values 1e-6) against the oracle's omp_CSR_SpMM restatement, and against the summary the REAL reference produced for
+    the same input (tests/golden/golden_large.json, tests/golden/make_golden_web.py); also the classification (hv)."""
+    import json
+    g = json.load(open(os.path.join(GOLDEN, "golden_large.json")))["web_surrogate_916428_46"]
+    from sparse_matrix_with_flops_amd import synth
+    rp, ci, v = synth.webgraph_csr(g["m"], g["seed"])
+    A = po.CSRHost(rp, ci, v, g["m"], g["m"])
+    assert A.nnz == g["nnzA"]
+    dA = to_hs(A).toGpuCSR()
+    hv, hv_len, ids, fl, tot = hs.gpuFlopsClassify(dA, dA, handle)
+    hs.dev_free(ids)
+    hs.dev_free(fl)
+    assert tot == g["P"] and [int(x) for x in hv[:hv_len]] == g["hv"][:g["hv_len"]]
+    dC = hs.gpuSpMMWrapper(dA, dA, handle)
+    st = handle.stats()
+    assert st["total_flops"] == g["P"] and st["nnzC"] == g["nnz"]
+    assert 0.45 <= st["nnzC"] / st["total_flops"] <= 0.55
+    got = dC.toCpuCSR()
+    dC.deviceDispose()
+    dA.deviceDispose()
+    s = summarize(got)
+    assert s["nnz"] == g["nnz"] and s["hash"] == g["hash"]
+    assert abs(s["sum"] - g["sum"]) <= 1e-6 * abs(g["sum"]) and abs(s["wsum"] - g["wsum"]) <= 1e-6 * abs(g["wsum"])
+    want = po.omp_spmm(A, A)
+    assert_parity(got, want, what="web-Google surrogate A*A")
+
+
 @pytest.mark.skipif(not os.environ.get("SPGEMM_WEB_GOOGLE_MTX"), reason="set SPGEMM_WEB_GOOGLE_MTX=/path/to/web-Google.mtx")
 def test_config2_web_google_known_totals(handle):
     """BASELINE configs[2]: SuiteSparse web-Google is on neither box; when a copy is supplied by environment variable,
