@@ -274,17 +274,10 @@ __device__ __forceinline__ void hash_accum(slot_t* tab, int size, int shift, int
 
 // U products per lane in lock step, wave-uniform control flow.  Lanes without work aim their CAS at a private
 // 8-byte dummy (a CAS costs the same with any lane count; the float add below does not, hence its EXEC mask).
-// Repeated columns: the add.  ds_add_f32 costs ~3 cycles per ACTIVE lane, a 64-bit CAS 9-23 per wave instruction whatever
-// the lane count.  Where most products of a round meet a column that is already there (real web graphs, late R-MCL
-// iterations: nnz(C)/P ~ 0.5) the add is therefore done by a CAS on the whole slot {key, value + v}, starting from the
-// slot content the insert CAS returned; lanes of one round that hit the same slot retry (they are served one after the
-// other by the LDS, each failure returns the fresh content).  With few repeated columns the float add stays.
-constexpr slot_t NEVER_SLOT = 0x0000000080000001ull;     // matches neither a table slot nor the dummy words
-#ifndef SMF_CASADD_MIN
-#define SMF_CASADD_MIN 16
-#endif
-constexpr int CASADD_MIN_LANES = SMF_CASADD_MIN;      // repeated columns per round (of 64) from which the CAS add pays
-
+// (Round 3, measured and kept out: adding the repeated columns by a 64-bit CAS on the whole slot {key, value + v} instead of
+// ds_add_f32 -- 3 cycles per active lane -- for rounds where most products repeat a column (nnz(C)/P ~ 0.5).  The slot
+// content the insert CAS returned has to be carried per product: +2U VGPRs in every numeric kernel.  Web-graph surrogate:
+// k_num_hash<1,*> 0.308 -> 0.478 ms; headline matrix 0.293 -> 0.366 ms.  profiles/README.md, round 3.)
 template <bool POW2 = true, int U>
 __device__ __forceinline__ void hash_accum_multi(slot_t* tab, int size, int shift, const bool (&act)[U],
                                                  const int (&col)[U], const float (&val)[U], slot_t* dummy, int* err) {
@@ -292,7 +285,7 @@ __device__ __forceinline__ void hash_accum_multi(slot_t* tab, int size, int shif
   const int dumB = (int)(reinterpret_cast<char*>(dummy) - base);
   const int maskB = size * 8 - 1, sizeB = size * 8;
   int hB[U], stepB[U], dupB[U];                   // byte offsets; dumB = "done" / "no repeated column"
-  slot_t mine[U], seen[U];                        // seen: the slot as the insert CAS found it when the key matched
+  slot_t mine[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const unsigned hv = (unsigned)col[u] * 2654435761u;
@@ -302,7 +295,6 @@ __device__ __forceinline__ void hash_accum_multi(slot_t* tab, int size, int shif
     hB[u] = act[u] ? (int)(h * 8u) : dumB;
     dupB[u] = dumB;
     mine[u] = make_slot(col[u], val[u]);
-    seen[u] = NEVER_SLOT;
   }
   int probe = 0;
   for (;;) {                                        // first round unconditional: the col and value gathers stay together
@@ -317,7 +309,6 @@ __device__ __forceinline__ void hash_accum_multi(slot_t* tab, int size, int shif
       const bool same = pend && slot_key(old[u]) == col[u];
       const bool adv = pend && old[u] != EMPTY_SLOT && slot_key(old[u]) != col[u];
       dupB[u] = same ? hB[u] : dupB[u];
-      seen[u] = same ? old[u] : seen[u];
       int nh;
       if (POW2) nh = (hB[u] + probe * 8) & maskB;            // triangular steps
       else { nh = hB[u] + stepB[u]; nh = nh >= sizeB ? nh - sizeB : nh; }
@@ -327,31 +318,9 @@ __device__ __forceinline__ void hash_accum_multi(slot_t* tab, int size, int shif
     if (anyPend == 0ull) break;
     if (probe >= size) { atomicOr(err, ERRF_TABLE_FULL); break; }
   }
-  int ndup = 0;
 #pragma unroll
-  for (int u = 0; u < U; ++u) ndup += __popcll(ballot64(dupB[u] != dumB));
-  if (ndup < CASADD_MIN_LANES * U) {                // wave-uniform
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (dupB[u] != dumB) atomicAdd(reinterpret_cast<float*>(base + dupB[u] + 4), val[u]);
-    return;
-  }
-  for (int guard = 0; guard < 64 * U + 8; ++guard) {   // a slot shared by k lanes of the round takes k turns
-    slot_t got[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      got[u] = atomicCAS(reinterpret_cast<slot_t*>(base + dupB[u]), seen[u], make_slot(col[u], slot_val(seen[u]) + val[u]));
-    unsigned long long more = 0ull;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const bool pend = dupB[u] != dumB;
-      const bool done = got[u] == seen[u];
-      dupB[u] = (pend && !done) ? dupB[u] : dumB;
-      seen[u] = (pend && !done) ? got[u] : NEVER_SLOT;
-      more |= ballot64(dupB[u] != dumB);
-    }
-    if (more == 0ull) break;
-  }
+  for (int u = 0; u < U; ++u)
+    if (dupB[u] != dumB) atomicAdd(reinterpret_cast<float*>(base + dupB[u] + 4), val[u]);
 }
 
 // float add into an LDS word by read + 32-bit CAS (retry on interference): ~2 cheap LDS ops instead of a

@@ -200,6 +200,9 @@ struct spgemm_handle {
   int h1sym = 32;                    // blocks per CU of the wave-per-row symbolic kernel (SPGEMM_H1SYM, experiments)
   spgemm_stats stats;
   spgemm_host_api_stats host_api = {};   // phases of the latest hip_CSR_SpMM
+  int prev_m = -1;                   // shape and sizes of the previous one-shot SpGEMM (allocation policy of the next one)
+  unsigned long long prev_P = 0;
+  long long prev_nnzC = -1;
 };
 
 static std::mutex g_count_mu;
@@ -717,7 +720,12 @@ static int spgemm_device(spgemm_handle* h, const int* dIA, const int* dJA, const
       return cleanup(fail(SPGEMM_ERR_HIP, "classification failed: %s", hipGetErrorString(hipGetLastError())));
     const HostMirror mid = *h->hmid;
     const unsigned long long P = mid.totalP;
-    if (P <= (1ull << 30)) {
+    // A product that compresses (real web graphs: nnz(C)/P ~ 0.5) would hold twice the memory it needs when sized by P.
+    // The handle remembers the previous call: the same shape and product count with nnz(C) < 3/4 P sends this call down
+    // the two-phase path (exact allocation, one more host round trip -- cheap next to the halved footprint).
+    const bool compressive = h->prev_m == m && h->prev_P == P && h->prev_nnzC >= 0 &&
+                             (double)h->prev_nnzC < 0.75 * (double)P;
+    if (P <= (1ull << 30) && !compressive) {
       const size_t capC = (size_t)std::max<unsigned long long>(P, 1ull);
       if (hipSuccess != pool().alloc((void**)&dJC, sizeof(int) * capC) ||
           hipSuccess != pool().alloc((void**)&dC, sizeof(float) * capC))
@@ -747,6 +755,7 @@ static int spgemm_device(spgemm_handle* h, const int* dIA, const int* dJA, const
       hipEventElapsedTime(&st.ms_total, h->ev[0], h->ev[5]);
       collect_kernel_times(h, true);
       grow_bitmaps(h, n);
+      h->prev_m = m; h->prev_P = P; h->prev_nnzC = (long long)hm.nnzC64;
       *dICp = dIC; *dJCp = dJC; *dCp = dC; *nnzCp = (int)hm.nnzC64;
       return SPGEMM_OK;
     }
@@ -760,10 +769,14 @@ static int spgemm_device(spgemm_handle* h, const int* dIA, const int* dJA, const
     h->stats.total_flops = (long long)h->mirror.totalP;
     h->stats.nnzC = (int)h->mirror.nnzC64;
     for (int b = 0; b < NBINS; ++b) h->stats.bin_rows[b] = h->mirror.binPtr[b + 1] - h->mirror.binPtr[b];
-    h->stats.ms_total = 0.f;
+    hipEventElapsedTime(&h->stats.ms_classify, h->ev[0], h->ev[1]);
+    hipEventElapsedTime(&h->stats.ms_symbolic, h->ev[1], h->ev[2]);
+    hipEventElapsedTime(&h->stats.ms_scan_alloc, h->ev[2], h->ev[3]);
+    h->stats.ms_total = h->stats.ms_classify + h->stats.ms_symbolic + h->stats.ms_scan_alloc;
     collect_kernel_times(h, true);
     h->sym_m = m;
     nnzC = (int)h->mirror.nnzC64;
+    h->prev_m = m; h->prev_P = P; h->prev_nnzC = nnzC;
     if (hipSuccess != pool().alloc((void**)&dJC, sizeof(int) * (size_t)std::max(nnzC, 1)) ||
         hipSuccess != pool().alloc((void**)&dC, sizeof(float) * (size_t)std::max(nnzC, 1)))
       return cleanup(fail(SPGEMM_ERR_HIP, "device allocation of C (%d entries) failed", nnzC));

@@ -202,3 +202,47 @@ def test_host_array_entry_point_moves_large_arrays_through_the_copy_lanes():
     B = synth_csr(100003, 29, 2)
     got = hA.hip_spmm(to_hs(B))
     assert_parity(got, po.omp_spmm(A, B), what="host API, A != B")
+
+
+def test_compressive_product_is_not_held_at_twice_its_size():
+    """hip_gpuSpMM sizes C by the product count P (an upper bound: no host round trip between its phases).  For a product
+    that compresses -- web graphs: nnz(C)/P ~ 0.5 -- that is twice the memory; from the second call on the same shape the
+    handle takes the two-phase path and allocates nnz(C) entries exactly.  Checked through the pool: the blocks C gives
+    back when it is freed."""
+    from sparse_matrix_with_flops_amd import synth
+    m = 120000
+    rp, ci, v = synth.webgraph_csr(m, 7)
+    A = po.CSRHost(rp, ci, v, m, m)
+    want = po.omp_spmm(A, A)
+    P = int(po.row_flops(A, A).sum())
+    assert want.nnz < 0.6 * P
+    h = hs.Handle(0)
+    dA = to_hs(A).toGpuCSR()
+    from helpers import assert_parity
+    # call 0 is sized by P; its C stays alive, so that the later calls cannot be handed its (larger) blocks by the pool
+    dC0 = hs.gpuSpMMWrapper(dA, dA, h)
+    sizes = []
+    for call in (1, 2):
+        dC = hs.gpuSpMMWrapper(dA, dA, h)
+        mid = hs.pool_cached_bytes(0)
+        got = dC.toCpuCSR()
+        dC.deviceDispose()
+        sizes.append(hs.pool_cached_bytes(0) - mid)    # bytes the three arrays of this C occupied
+        assert_parity(got, want, what=f"compressive product, call {call}")
+    mid = hs.pool_cached_bytes(0)
+    assert_parity(dC0.toCpuCSR(), want, what="compressive product, call 0")
+    dC0.deviceDispose()
+    size0 = hs.pool_cached_bytes(0) - mid
+    assert size0 >= 8 * P                              # first call: sized by P
+    assert sizes[0] <= 8 * want.nnz + 4 * (m + 1) + (8 << 20)      # from then on: exact (+ rounding of three blocks)
+    # a non-compressive product keeps the one-shot path
+    B = synth_csr(60000, 3, 2)
+    dB = to_hs(B).toGpuCSR()
+    for call in range(2):
+        dC = hs.gpuSpMMWrapper(dB, dB, h)
+        st = h.stats()
+        dC.deviceDispose()
+    assert st["nnzC"] > 0.75 * st["total_flops"]
+    dA.deviceDispose()
+    dB.deviceDispose()
+    h.close()

@@ -134,6 +134,34 @@ def test_headline_1m_instance_numbers():
     assert [int(x) for x in po.equal_partition64(pref, 8)] == g["partition8"]
 
 
+def test_web_surrogate_instance_numbers_and_oracle_product():
+    """BASELINE configs[2] by shape (synth.webgraph_csr, 916 428 rows): the generator is pinned (nnzA, P, degrees) and the
+    oracle's OpenMP restatement reproduces the summary the REAL reference's omp_CSR_SpMM made for this input
+    (tests/golden/make_golden_web.py -> golden_large.json); nnz(C)/P lands in the compressive band the surrogate exists
+    for.  The totals the reference tree records for the real web-Google stay unpinned (the file is in neither container)."""
+    import json
+    import os
+    from helpers import GOLDEN, synth
+    g = json.load(open(os.path.join(GOLDEN, "golden_large.json")))["web_surrogate_916428_46"]
+    rp, ci, v = synth.webgraph_csr(g["m"], g["seed"])
+    A = po.CSRHost(rp, ci, v, g["m"], g["m"])
+    assert A.nnz == g["nnzA"] and int(np.diff(rp).max()) == g["max_out_degree"]
+    assert int(np.bincount(ci, minlength=g["m"]).max()) == g["max_in_degree"]
+    f = po.row_flops(A, A)
+    assert int(f.sum()) == g["P"] and int(f.max()) == g["max_row_flops"]
+    rowIds, scan, hv, n = po.gpu_classify(f)
+    assert [int(x) for x in hv] == g["hv"] and n == g["hv_len"]
+    pref = np.concatenate([[0], np.cumsum(f)])
+    assert [int(x) for x in po.equal_partition64(pref, 8)] == g["partition8"]
+    s = summarize(po.omp_spmm(A, A))
+    assert s["nnz"] == g["nnz"] and s["hash"] == g["hash"]
+    assert abs(s["sum"] - g["sum"]) <= 1e-9 * abs(g["sum"]) and abs(s["wsum"] - g["wsum"]) <= 1e-9 * abs(g["wsum"])
+    assert 0.45 <= s["nnz"] / g["P"] <= 0.55
+    real = g["real_web_google_totals_res_txt_1910"]                       # shape, not identity
+    assert real["N"] == g["m"] and abs(g["nnzA"] - real["nnzA"]) <= 0.05 * real["nnzA"]
+    assert abs(2 * g["P"] - real["flops_2P"]) <= 0.10 * real["flops_2P"] and abs(g["nnz"] - real["nnzC"]) <= 0.10 * real["nnzC"]
+
+
 def test_gpu_bin_ids_and_classify():
     # dqueueId edges (mindex2-cuda/flops.cu:39-47)
     L = po.lib()
