@@ -302,11 +302,16 @@ def bench_spgemm(ctx, args, wl):
     # BENCH_FORCE_GROUP=1: rehearsal of the N>1 plumbing on one GPU (a group of ONE rank: its segment makes the round trip
     # through the library's RCCL transport to itself)
     if (world > 1 and args.backend == "nccl" and not args.torch_exchange) or os.environ.get("BENCH_FORCE_GROUP"):
-        try:
-            runner = GroupRunner(ctx, host)
-        except Exception as e:                                            # noqa: BLE001 -- any failure: the other transport
-            fallback = f"{type(e).__name__}: {e}"
-            runner = None
+        # every rank first checks that it can load RCCL at all: a rank that cannot must not leave the others waiting for
+        # it inside ncclCommInitRank
+        if not ctx.all_ok(hs.rccl_available()):
+            fallback = "librccl could not be loaded on every rank: " + hs.lib().spgemm_hip_last_error().decode(errors="replace")
+        else:
+            try:
+                runner = GroupRunner(ctx, host)
+            except Exception as e:                                        # noqa: BLE001 -- any failure: the other transport
+                fallback = f"{type(e).__name__}: {e}"
+                runner = None
         if not ctx.all_ok(runner is not None):
             runner = None
             fallback = fallback or "another rank could not create its group"

@@ -224,6 +224,7 @@ int hip_gpuRmclIter(int maxIter, int rows, int cols,
 typedef struct spgemm_group spgemm_group;
 typedef struct spgemm_sharded spgemm_sharded;
 int spgemm_hip_group_create(spgemm_group** g, int nshards, const int* devices, int transport);
+int spgemm_hip_rccl_available(void);          /* SPGEMM_OK when librccl loads in this process (ask on every rank first) */
 int spgemm_hip_unique_id(void* id128);
 int spgemm_hip_group_create_rank(spgemm_group** g, int nranks, int rank, int device, const void* id128);
 int spgemm_hip_group_info(const spgemm_group* g, int* nranks, int* nlocal, int* transport);

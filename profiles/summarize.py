@@ -4,8 +4,9 @@
    profiles/<tag>_<workload>_traffic.json        per kernel: avg FETCH_SIZE / WRITE_SIZE per launch -> HBM bytes
 Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are reported in KiB by
 rocprofv3; on gfx950 FETCH_SIZE counts 64 B per 128 B request for wide coalesced streams (x2 correction).  This path
-gathers 4-byte elements in short runs, an access width the guide calls uncalibrated, so BOTH the raw and the x2 figure
-are recorded and bench.py reports the raw one ("fetch_correction": 1.0) — treat it as a lower bound on read traffic."""
+gathers 4-byte elements in short runs; the TCC/EA counters (profiles/*tcc_counters*) show that every fabric read request of
+these kernels is a 128-byte one, so the x2 correction applies: bench.py reports the x2 figure as roofline.traffic
+(traffic_fetch_x2) and the uncorrected sum beside it (traffic_raw)."""
 import collections
 import csv
 import glob

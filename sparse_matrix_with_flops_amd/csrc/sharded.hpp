@@ -182,6 +182,14 @@ extern "C" int spgemm_hip_group_create(spgemm_group** out, int nshards, const in
   return SPGEMM_OK;
 }
 
+// SPGEMM_OK when librccl could be loaded into this process (every rank of a multi-process job asks before any of them
+// enters ncclCommInitRank, where a missing peer means waiting forever)
+extern "C" int spgemm_hip_rccl_available(void) {
+  RcclApi& R = rccl();
+  if (!R.ok) return fail(SPGEMM_ERR_HIP, "RCCL is not available: %s", R.why.c_str());
+  return SPGEMM_OK;
+}
+
 extern "C" int spgemm_hip_unique_id(void* id128) {
   if (!id128) return fail(SPGEMM_ERR_ARG, "id buffer is null");
   static_assert(sizeof(ncclUniqueId) == SPGEMM_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");

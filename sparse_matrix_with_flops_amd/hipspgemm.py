@@ -39,7 +39,7 @@ EXPORTS = [
     "spgemm_hip_group_create", "spgemm_hip_unique_id", "spgemm_hip_group_create_rank", "spgemm_hip_group_info",
     "spgemm_hip_group_destroy", "hip_sharded_spmm_create", "hip_sharded_spmm_step", "hip_sharded_spmm_result",
     "hip_sharded_spmm_info", "hip_sharded_spmm_destroy", "hip_gpuRmclIter_sharded", "spgemm_hip_host_api_stats",
-    "hip_sharded_spmm_handle",
+    "hip_sharded_spmm_handle", "spgemm_hip_rccl_available",
 ]
 XCHG_AUTO, XCHG_RCCL, XCHG_PEER, XCHG_HOST = 0, 1, 2, 3
 XCHG_NAMES = {0: "auto", 1: "rccl", 2: "peer", 3: "host"}
@@ -536,6 +536,11 @@ def gpuRmclIter(maxIter, Mgt, Mt):
 # ---------------------------------------------------------------------------------------------
 # multi-GPU behind the C ABI (include/spgemm_hip.h "multi-GPU"): groups of shards, sharded SpGEMM, sharded R-MCL
 # ---------------------------------------------------------------------------------------------
+def rccl_available():
+    """True when the library could load librccl into this process"""
+    return lib().spgemm_hip_rccl_available() == 0
+
+
 def unique_id():
     """128-byte RCCL id made by rank 0 of a multi-process job; hand it to every rank (bytes)."""
     buf = C.create_string_buffer(UNIQUE_ID_BYTES)
