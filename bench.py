@@ -54,6 +54,28 @@ WORKLOADS = {
     "rmcl_20k": dict(m=20000, seed=91, base=2, gen="rmcl", iters=3, desc="R-MCL, 20000 nodes, 3 iterations (smoke-sized)"),
 }
 
+# The contract is ONE JSON line on stdout.  Libraries in this process print there too (RCCL's version banner, the reference's
+# own printf progress lines inside the cpu_baseline call): file descriptor 1 is pointed at stderr for the whole run and the
+# result line goes to the saved descriptor.
+_REAL_STDOUT = None
+
+
+def protect_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        print(line)
+        return
+    os.write(_REAL_STDOUT, (line + "\n").encode())
+
+
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 ALL_KERNELS = 0xFFFFF
 
@@ -118,7 +140,7 @@ def self_launch(args):
     got = json.loads(line)
     if got.get("n_gpus") != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the process group had {got.get('n_gpus')} ranks")
-    print(line)
+    emit(line)
     raise SystemExit(0)
 
 
@@ -240,37 +262,36 @@ class TorchRunner:
 
 
 class GroupRunner:
-    """N > 1 behind the C ABI: one-shard group per process (spgemm_hip_group_create_rank), RCCL inside the library"""
+    """N > 1 behind the C ABI (dist.library_group / LibraryShardedSpGEMM): one-shard group per process
+    (spgemm_hip_group_create_rank), partition, pipeline and the RCCL exchange inside the library"""
 
     def __init__(self, ctx, host):
-        hs = ctx.hs
-        rp, ci, v, m, _ = host
-        ident = ctx.broadcast_bytes(hs.unique_id() if ctx.rank == 0 else b"", hs.UNIQUE_ID_BYTES)
-        self.group = hs.Group.of_rank(ctx.world, ctx.rank, ctx.local_rank, ident)
-        self.hA = hs.CSR.from_arrays(rp, ci, v, m, m)
-        self.job = hs.ShardedSpMM(self.group, self.hA)
-        self.handles = [self.job.handle(0)]
-        self.handles[0].selftest()
+        from sparse_matrix_with_flops_amd.dist import LibraryShardedSpGEMM, library_group
         self.ctx = ctx
+        self.group = library_group(ctx.local_rank)
+        self.sh = LibraryShardedSpGEMM(self.group, host)
+        self.hA = self.sh.hA
+        self.handles = [self.sh.handle]
+        self.handles[0].selftest()
         self.P = None
-        self.nnz = 0
         self.transport = "rccl inside libspgemm_hip.so (spgemm_hip_group_create_rank): grouped ncclSend/ncclRecv per peer"
 
     def step(self, gather):
-        self.nnz, self.P = self.job.step(gather)
+        self.sh.step(gather)
+        self.P = self.sh.total_flops
 
     def device_ms(self):
-        return self.job.info()["ms_compute"]
+        return self.sh.info()["ms_compute"]
 
     def local_nnz(self):
-        return int(self.nnz)
+        return int(self.sh.nnz)
 
     def result_host(self):
-        c = self.job.result(0)
+        c = self.sh.result_host()
         return c.rowPtr, c.colInd, c.values
 
     def local_rows(self):
-        e = self.job.info()["ends"]
+        e = self.sh.info()["ends"]
         return e[self.ctx.rank], e[self.ctx.rank + 1]
 
     def local_row_flops(self):
@@ -302,16 +323,11 @@ def bench_spgemm(ctx, args, wl):
     # BENCH_FORCE_GROUP=1: rehearsal of the N>1 plumbing on one GPU (a group of ONE rank: its segment makes the round trip
     # through the library's RCCL transport to itself)
     if (world > 1 and args.backend == "nccl" and not args.torch_exchange) or os.environ.get("BENCH_FORCE_GROUP"):
-        # every rank first checks that it can load RCCL at all: a rank that cannot must not leave the others waiting for
-        # it inside ncclCommInitRank
-        if not ctx.all_ok(hs.rccl_available()):
-            fallback = "librccl could not be loaded on every rank: " + hs.lib().spgemm_hip_last_error().decode(errors="replace")
-        else:
-            try:
-                runner = GroupRunner(ctx, host)
-            except Exception as e:                                        # noqa: BLE001 -- any failure: the other transport
-                fallback = f"{type(e).__name__}: {e}"
-                runner = None
+        try:                                                              # (library_group asks every rank for RCCL first)
+            runner = GroupRunner(ctx, host)
+        except Exception as e:                                            # noqa: BLE001 -- any failure: the other transport
+            fallback = f"{type(e).__name__}: {e}"
+            runner = None
         if not ctx.all_ok(runner is not None):
             runner = None
             fallback = fallback or "another rank could not create its group"
@@ -477,10 +493,10 @@ def bench_spgemm(ctx, args, wl):
             result["parity"] = ("ok (rowPtr, sorted colInd bit-exact; values rel<=1e-6 vs CPU oracle"
                                 + (f"; gathered C of {world} ranks checked on rank 0)" if world > 1 else ")")) if ok else "FAILED"
             if not ok:
-                print(json.dumps(result))
+                emit(json.dumps(result))
                 raise SystemExit("parity gate failed")
         result["setup"] = {"generate_s": round(gen_s, 2), "host_cpus": os.cpu_count()}
-        print(json.dumps(result))
+        emit(json.dumps(result))
     runner.release()
 
 
@@ -504,8 +520,8 @@ def bench_rmcl(ctx, args, wl):
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_large.json"))).get(f"rmcl_{m}_{wl['seed']}")
 
     if world > 1:
-        ident = ctx.broadcast_bytes(hs.unique_id() if rank == 0 else b"", hs.UNIQUE_ID_BYTES)
-        grp = hs.Group.of_rank(world, rank, ctx.local_rank, ident)
+        from sparse_matrix_with_flops_amd.dist import library_group
+        grp = library_group(ctx.local_rank)
         for _ in range(max(1, args.warmup)):
             R = hs.gpuRmclIter_sharded(grp, iters, H, H)
         ctx.barrier()
@@ -517,7 +533,7 @@ def bench_rmcl(ctx, args, wl):
         if rank == 0:
             # products per iteration: the reference-made summary holds nnz of the raw products, not P; the 1-GPU run reports P
             ms = elapsed * 1e3 / args.steps
-            print(json.dumps({
+            emit(json.dumps({
                 "metric": "R-MCL loop wall time (host arrays in/out)", "value": round(ms, 3), "unit": "ms", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": False,
                 "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -616,7 +632,7 @@ def bench_rmcl(ctx, args, wl):
         result["parity"] = (f"ok (rows sum to 1; nnz after {iters} iterations within the threshold-tie drift of the reference "
                             "summary; step-by-step parity: tests/test_gpu_rmcl.py)") if ok else "FAILED"
         if not ok:
-            print(json.dumps(result))
+            emit(json.dumps(result))
             raise SystemExit("parity gate failed")
     if not args.no_cpu_baseline:
         if po.have_ref():                                                  # the reference's own multi-threaded loop, 2 iterations
@@ -635,7 +651,7 @@ def bench_rmcl(ctx, args, wl):
                                       "sample": f"seqRmclIter restatement, first iteration only ({per[0]['P']} products), {dt * 1e3:.0f} ms",
                                       "ms": round(dt * 1e3, 1)}
     result["setup"] = {"generate_s": round(gen_s, 2), "host_cpus": os.cpu_count()}
-    print(json.dumps(result))
+    emit(json.dumps(result))
     h.close()
 
 
@@ -662,6 +678,7 @@ def main():
                     help="keep the HIP events of every kernel inside the timed region (diagnostic; costs ~3 %% of a step)")
     args = ap.parse_args()
     os.environ.setdefault("OMP_NUM_THREADS", str(os.cpu_count() or 1))   # cpu_baseline: all host threads
+    protect_stdout()
     ctx = Ctx(args)
     wl = WORKLOADS[args.workload]
     if wl.get("gen") == "rmcl":

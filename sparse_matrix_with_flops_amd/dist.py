@@ -1,5 +1,13 @@
 """Row-sharded multi-GPU SpGEMM: A split into flops-balanced contiguous row blocks, B replicated,
-C's row segments exchanged with an allgatherv over RCCL/xGMI (torch.distributed, one process per GPU).
+C's row segments exchanged with an allgatherv over RCCL/xGMI (one process per GPU).
+
+Two implementations live here.  (1) `library_group` / `LibraryShardedSpGEMM` / `library_rmcl`: thin callers of the C ABI's
+own multi-GPU entry points (include/spgemm_hip.h "multi-GPU", csrc/sharded.hpp) -- torch.distributed only carries the
+128-byte RCCL id from rank 0 to the others; partition, per-shard pipeline, size exchange and the grouped ncclSend/ncclRecv
+all run inside libspgemm_hip.so.  This is what bench.py --gpus N runs.  (2) `ShardedSpGEMM` / `ShardedRMCL`: the same
+control flow written at the Python level over torch.distributed collectives with a pluggable local engine; it runs on
+gloo with the CPU oracle as engine (tests/test_dist_gloo.py: the N>1 logic on a box without GPUs) and is bench.py's
+fallback when the library's group cannot be made.
 
 The reference has no multi-device code at all; what it does have is the same idea across
 CPU threads: rows are cut into contiguous ranges of equal *flops* with arrayEqualPartition64
@@ -170,6 +178,56 @@ def make_matrix(engine, rowPtr, colInd, values, rows, cols):
     return {"rowPtr": engine.tensor(rowPtr, torch.int32), "colInd": engine.tensor(colInd, torch.int32),
             "values": engine.tensor(values, torch.float32), "rows": int(rows), "cols": int(cols),
             "nnz": int(rowPtr[-1]) if len(rowPtr) else 0}
+
+
+def library_group(device_index, group=None):
+    """This process's one-shard spgemm_group (hs.Group.of_rank): rank 0 makes the RCCL id inside the library, the id
+    travels over the torch.distributed group, every rank then creates its shard.  Every rank first checks that the
+    library can load RCCL at all (a rank that cannot must not leave the others waiting inside ncclCommInitRank)."""
+    world = dist.get_world_size(group) if (dist and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if (dist and dist.is_initialized()) else 0
+    ok = torch.tensor([0 if hs.rccl_available() else 1], dtype=torch.int32,
+                      device=("cuda" if world > 1 and dist.get_backend(group) == "nccl" else "cpu"))
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MAX, group=group)
+    if int(ok.item()) != 0:
+        raise hs.SpgemmError("librccl could not be loaded on every rank")
+    ident = hs.unique_id() if rank == 0 else bytes(hs.UNIQUE_ID_BYTES)
+    if world > 1:
+        t = torch.tensor(list(ident), dtype=torch.uint8, device=ok.device)
+        dist.broadcast(t, 0, group=group)
+        ident = bytes(t.cpu().tolist())
+    return hs.Group.of_rank(world, rank, device_index, ident)
+
+
+class LibraryShardedSpGEMM:
+    """C = A * B row-sharded over the ranks, entirely behind the C ABI (hip_sharded_spmm_*).  A_host / B_host:
+    (rowPtr, colInd, values, rows, cols) numpy tuples, identical on every rank; B_host=None means C = A*A."""
+
+    def __init__(self, lib_group, A_host, B_host=None):
+        self.group = lib_group
+        self.hA = hs.CSR.from_arrays(*A_host)
+        self.hB = hs.CSR.from_arrays(*B_host) if B_host is not None else None
+        self.job = hs.ShardedSpMM(lib_group, self.hA, self.hB)
+        self.handle = self.job.handle(0)
+        self.nnz, self.total_flops = 0, None
+
+    def step(self, gather=True):
+        """one hot-path pass; -> nnz of the gathered C (gather=False: of this rank's block)"""
+        self.nnz, self.total_flops = self.job.step(gather)
+        return self.nnz
+
+    def result_host(self):
+        """what this rank holds after the last step: the whole C (gathered) or its own block, as an hs.CSR"""
+        return self.job.result(0)
+
+    def info(self):
+        return self.job.info()
+
+
+def library_rmcl(lib_group, maxIter, Mgt_host, Mt_host):
+    """gpuRmclIter over the ranks behind the C ABI (hip_gpuRmclIter_sharded); every rank gets the whole result."""
+    return hs.gpuRmclIter_sharded(lib_group, maxIter, hs.CSR.from_arrays(*Mgt_host), hs.CSR.from_arrays(*Mt_host))
 
 
 class ShardedSpGEMM:

@@ -149,3 +149,24 @@ def test_cpp_driver_runs_the_sharded_loop():
     assert out.returncode == 0, out.stdout + out.stderr
     assert "Same" in out.stdout and "Diffs" not in out.stdout
     assert "time pass readSNAPFile" in out.stdout and "time pass gpuRmclIter" in out.stdout
+
+
+def test_dist_module_calls_the_library_entry_points():
+    """dist.library_group / LibraryShardedSpGEMM / library_rmcl -- what bench.py --gpus N runs on every rank -- with a world
+    of one: the group comes from spgemm_hip_group_create_rank, the segment makes its round trip through RCCL."""
+    import torch  # noqa: F401  (the torch runtime first: tests/conftest.py)
+    from sparse_matrix_with_flops_amd.dist import LibraryShardedSpGEMM, library_group, library_rmcl
+    A = synth_csr(30000, 41, 2)
+    g = library_group(0)
+    assert (g.nranks, g.nlocal, g.transport) == (1, 1, hs.XCHG_RCCL)
+    job = LibraryShardedSpGEMM(g, (A.rowPtr, A.colInd, A.values, A.rows, A.cols))
+    want = po.omp_spmm(A, A)
+    assert job.step(gather=True) == want.nnz and job.total_flops == int(po.row_flops(A, A).sum())
+    assert_parity(job.result_host(), want, what="LibraryShardedSpGEMM, world 1")
+    st = job.handle.stats()
+    assert st["nnzC"] == want.nnz and job.info()["ends"] == [0, A.rows]
+    Mt = _graph(8000, 13)
+    host = (Mt.rowPtr, Mt.colInd, Mt.values, Mt.rows, Mt.cols)
+    nxt = library_rmcl(g, 1, host, host)
+    assert_rmcl_step(po.CSRHost(nxt.rowPtr, nxt.colInd, nxt.values, Mt.rows, Mt.cols), Mt, Mt, what="library_rmcl, world 1")
+    g.close()
