@@ -539,7 +539,7 @@ extern "C" int hip_sharded_spmm_step(spgemm_sharded* job, int gather, long long*
     auto& L = job->loc[i];
     HIPCHK(hipSetDevice(s.device));
     int nz = 0;
-    CHK(symbolic_phase(s.h, L.A.I, L.A.J, L.A.nnz, L.B.I, L.B.J, L.A.rows, job->k, job->n, nullptr, L.lIC, &nz, L.B.nnz));
+    CHK(symbolic_phase(s.h, L.A.I, L.A.J, L.A.nnz, L.B.I, L.B.J, L.A.rows, job->k, job->n, nullptr, L.lIC, &nz));
     localNnz[i] = nz;
     return SPGEMM_OK;
   }));
@@ -557,7 +557,7 @@ extern "C" int hip_sharded_spmm_step(spgemm_sharded* job, int gather, long long*
     HIPCHK(hipSetDevice(s.device));
     const long long off = doGather ? offs[(size_t)s.grank] : 0;
     CHK(ensure_cap(L, (size_t)std::max<long long>(doGather ? total : localNnz[i], 1)));
-    CHK(numeric_phase(s.h, L.A.I, L.A.J, L.A.V, L.B.I, L.B.J, L.B.V, L.A.rows, job->n, L.lIC, L.gJ + off, L.gV + off, L.B.nnz));
+    CHK(numeric_phase(s.h, L.A.I, L.A.J, L.A.V, L.B.I, L.B.J, L.B.V, L.A.rows, job->n, L.lIC, L.gJ + off, L.gV + off));
     const int r0 = doGather ? job->ends[s.grank] : 0;
     const int cnt = L.A.rows + ((!doGather || s.grank == G - 1) ? 1 : 0);
     if (cnt > 0) hipLaunchKernelGGL(k_offset_copy, dim3(cdiv(cnt, 256)), dim3(256), 0, s.h->stream, cnt, L.lIC, (int)off, L.gI + r0);

@@ -52,37 +52,6 @@ template <class T> __device__ __forceinline__ void st_out(T* p, T v) {
   __builtin_nontemporal_store(v, p);
 #endif
 }
-// B entries as the kernels gather them.  SMF_PACKED: the numeric kernels read ONE 8-byte {column, value bits} pair per
-// product from a packed copy of B (built once per SpGEMM by k_pack_b; its address travels in the VB argument) instead of
-// one 4-byte load from colInd and one from values: half the wave-loads and half the 128-byte lines per product.
-// SMF_PACKED_SYM: the symbolic kernels read their columns from the same packed copy (address in the JB argument), so that
-// it is the only B array the two passes touch.
-template <bool NEED_VAL>
-__device__ __forceinline__ void load_b(const int* __restrict__ JB, const float* __restrict__ VB, int jb, int& col, float& vb) {
-#ifdef SMF_PACKED
-  if (NEED_VAL) {
-    const int2 cv = reinterpret_cast<const int2*>(VB)[jb];
-    col = cv.x;
-    vb = __int_as_float(cv.y);
-    return;
-  }
-#endif
-#ifdef SMF_PACKED_SYM
-  if (!NEED_VAL) { col = reinterpret_cast<const int2*>(JB)[jb].x; vb = 0.f; return; }
-#endif
-  col = JB[jb];
-  vb = NEED_VAL ? VB[jb] : 0.f;
-}
-
-__global__ __launch_bounds__(256) void k_pack_b(int nnzB, const int* __restrict__ JB, const float* __restrict__ VB,
-                                                 int2* __restrict__ PB) {
-  for (int p = blockIdx.x * 256 + threadIdx.x; p < nnzB; p += gridDim.x * 256) PB[p] = make_int2(JB[p], __float_as_int(VB[p]));
-}
-
-__global__ __launch_bounds__(256) void k_pack_cols(int nnzB, const int* __restrict__ JB, int2* __restrict__ PB) {
-  for (int p = blockIdx.x * 256 + threadIdx.x; p < nnzB; p += gridDim.x * 256) PB[p] = make_int2(JB[p], 0);
-}
-
 constexpr int NBINS = 9;  // {0 | 1 | 2-4 | 5-16 | 17-64 | 65-512 | 513-2048 | 2049-4096 | >4096}
 constexpr int EMPTY_KEY = -1;
 
@@ -827,7 +796,8 @@ __device__ __forceinline__ void g16_walk(G16Stage& st, int gl, int as, int ae, c
       for (int u = 0; u < U; ++u) {                // straight-line, no branches around the gathers
         act[u] = (r0 + u) * 16 + gl < T;
         const int jb = st.off[e[u]] + p[u];
-        load_b<NEED_VAL>(JB, VB, jb, col[u], vb[u]);
+        col[u] = JB[jb];
+        vb[u] = NEED_VAL ? VB[jb] : 0.f;
         av[u] = NEED_VAL ? st.aval[e[u]] : 0.f;
       }
       __builtin_amdgcn_sched_barrier(0);           // all gathers issued before the first wait
@@ -1071,7 +1041,8 @@ __device__ __forceinline__ void short_trip(const char* rec, int T, int ns, int r
     const int jb = ra.x + p;
     if (ABL(2)) { col[u] = jb; vb[u] = 1.f; }
     else {
-    load_b<NEED_VAL>(JB, VB, jb, col[u], vb[u]);
+    col[u] = JB[jb];
+    vb[u] = NEED_VAL ? VB[jb] : 0.f;
     }
     av[u] = __int_as_float(ra.y);
   }
@@ -1096,7 +1067,8 @@ __device__ __forceinline__ void long_trip(int kb, int kl, float ka, int s0, cons
     const int jb = kb + min(p0, kl - 1);
     if (ABL(2)) { col[u] = jb; vb[u] = 1.f; }
     else {
-    load_b<NEED_VAL>(JB, VB, jb, col[u], vb[u]);
+    col[u] = JB[jb];
+    vb[u] = NEED_VAL ? VB[jb] : 0.f;
     }
   }
   __builtin_amdgcn_sched_barrier(0);

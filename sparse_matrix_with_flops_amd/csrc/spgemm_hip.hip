@@ -201,8 +201,6 @@ struct spgemm_handle {
   int h1sym = 32;                    // blocks per CU of the wave-per-row symbolic kernel (SPGEMM_H1SYM, experiments)
   spgemm_stats stats;
   spgemm_host_api_stats host_api = {};   // phases of the latest hip_CSR_SpMM
-  int2* packedB = nullptr;           // experiment builds (SMF_PACKED): {column, value bits} pairs of B, cap_packed entries
-  long long cap_packed = -1;
   int prev_m = -1;                   // shape and sizes of the previous one-shot SpGEMM (allocation policy of the next one)
   unsigned long long prev_P = 0;
   long long prev_nnzC = -1;
@@ -310,7 +308,6 @@ extern "C" int spgemm_hip_destroy(spgemm_handle* h) {
   hipFree(h->bigBitmaps);
   hipFree(h->spill);
   hipFree(h->sbl);
-  hipFree(h->packedB);
   hipFree(h->dsmall);
   hipHostFree(h->hsmall);
   hipHostFree(h->hmid);
@@ -468,36 +465,12 @@ static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, con
   return SPGEMM_OK;
 }
 
-// experiment builds only: the packed copy of B the kernels gather from (see load_b); vals may be null (columns only)
-static int launch_pack(spgemm_handle* h, const int* dJB, const float* dB, long long nnzB) {
-#if defined(SMF_PACKED) || defined(SMF_PACKED_SYM)
-  if (nnzB > h->cap_packed) {
-    hipFree(h->packedB);
-    h->packedB = nullptr; h->cap_packed = -1;
-    const long long cap = nnzB + nnzB / 8 + 1024;
-    HIPCHK(hipMalloc((void**)&h->packedB, sizeof(int2) * (size_t)cap));
-    h->cap_packed = cap;
-  }
-  if (nnzB > 0) {
-    if (dB) hipLaunchKernelGGL(k_pack_b, dim3(clampi(cdiv(nnzB, 256 * 4), 1, h->numCU * 16)), dim3(256), 0, h->stream, (int)nnzB, dJB, dB, h->packedB);
-    else hipLaunchKernelGGL(k_pack_cols, dim3(clampi(cdiv(nnzB, 256 * 4), 1, h->numCU * 16)), dim3(256), 0, h->stream, (int)nnzB, dJB, h->packedB);
-  }
-  HIPCHK(hipGetLastError());
-#else
-  (void)h; (void)dJB; (void)dB; (void)nnzB;
-#endif
-  return SPGEMM_OK;
-}
-
 // symbolic pass over bins 2..8 (bins 0/1 were preset by K1).  Bin sizes are not known on the host
 // here (no sync): grids are capped by the CU count and every block strides / dequeues over its bin.
 static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJB,
                            int m, int n, const int* rowIds, int* dIC) {
   const int2* sbl = h->sbl;
   if (m <= 0) return SPGEMM_OK;
-#ifdef SMF_PACKED_SYM
-  dJB = reinterpret_cast<const int*>(h->packedB);
-#endif
   const int* bp = h->dsmall->binPtr;
   int* err = &h->dsmall->err;
   int* qc = h->dsmall->qctr;
@@ -549,12 +522,6 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
   // pmode 2: no symbolic pass ran below bin 8: dIC holds the prefix sums of the rows' product counts there, exact counts
   // for the rows of bin 8
   const int2* sbl = h->sbl;
-#ifdef SMF_PACKED
-  dB = reinterpret_cast<const float*>(h->packedB);
-#endif
-#ifdef SMF_PACKED_SYM
-  dJB = reinterpret_cast<const int*>(h->packedB);
-#endif
   const int* bp = h->dsmall->binPtr;
   int* err = &h->dsmall->err;
   int* qc = h->dsmall->qctr;
@@ -634,14 +601,10 @@ static int unpack_classification(spgemm_handle* h, int m, const PreClass& pre, i
 
 // phase 1: classify + symbolic + scan; one host sync at the end (nnzC, bin sizes, error flags)
 static int symbolic_phase(spgemm_handle* h, const int* dIA, const int* dJA, int nnzA, const int* dIB, const int* dJB,
-                          int m, int k, int n, const PreClass* pre, int* dIC, int* nnzCp, long long nnzB = -1) {
+                          int m, int k, int n, const PreClass* pre, int* dIC, int* nnzCp) {
   (void)k;
   hipStream_t s = h->stream;
   hipEventRecord(h->ev[0], s);
-#ifdef SMF_PACKED_SYM
-  if (nnzB < 0) return fail(SPGEMM_ERR_ARG, "experiment build: symbolic phase needs nnz(B)");
-  CHK(launch_pack(h, dJB, nullptr, nnzB));
-#endif
   h->cur_rowIds = h->rowIds;
   if (pre) {
     CHK(unpack_classification(h, m, *pre, dIC));
@@ -694,13 +657,9 @@ static void grow_bitmaps(spgemm_handle* h, int n) {
 
 // phase 2: numeric into caller-provided dJC/dC; one host sync at the end (error flags)
 static int numeric_phase(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, const int* dIB,
-                         const int* dJB, const float* dB, int m, int n, const int* dIC, int* dJC, float* dC, long long nnzB = -1) {
+                         const int* dJB, const float* dB, int m, int n, const int* dIC, int* dJC, float* dC) {
   if (h->sym_m != m) return fail(SPGEMM_ERR_ARG, "numeric phase without a matching symbolic phase on this handle");
   hipStream_t s = h->stream;
-#ifdef SMF_PACKED
-  if (nnzB < 0) return fail(SPGEMM_ERR_ARG, "experiment build: numeric phase needs nnz(B)");
-  CHK(launch_pack(h, dJB, dB, nnzB));
-#endif
   const int nnzC = (int)h->mirror.nnzC64;
   hipEventRecord(h->ev[4], s);
   if (m > 0 && nnzC > 0) {
@@ -750,7 +709,6 @@ static int spgemm_device(spgemm_handle* h, const int* dIA, const int* dJA, const
     h->cur_rowIds = h->rowIds;
     int rc = launch_classify(h, dIA, dJA, dIB, m, nnzA, dIC);
     if (rc) return cleanup(rc);
-    if ((rc = launch_pack(h, dJB, dB, nnzB))) return cleanup(rc);          // (experiment builds only)
     hipEventRecord(h->ev[1], s);
     if (hipMemcpyAsync(h->hmid, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipEventRecord(h->evMid, s) != hipSuccess)
@@ -823,17 +781,17 @@ static int spgemm_device(spgemm_handle* h, const int* dIA, const int* dJA, const
     if (hipSuccess != pool().alloc((void**)&dJC, sizeof(int) * (size_t)std::max(nnzC, 1)) ||
         hipSuccess != pool().alloc((void**)&dC, sizeof(float) * (size_t)std::max(nnzC, 1)))
       return cleanup(fail(SPGEMM_ERR_HIP, "device allocation of C (%d entries) failed", nnzC));
-    rc = numeric_phase(h, dIA, dJA, dA, dIB, dJB, dB, m, n, dIC, dJC, dC, nnzB);
+    rc = numeric_phase(h, dIA, dJA, dA, dIB, dJB, dB, m, n, dIC, dJC, dC);
     if (rc) return cleanup(rc);
     *dICp = dIC; *dJCp = dJC; *dCp = dC; *nnzCp = nnzC;
     return SPGEMM_OK;
   }
-  int rc = symbolic_phase(h, dIA, dJA, nnzA, dIB, dJB, m, k, n, pre, dIC, &nnzC, nnzB);
+  int rc = symbolic_phase(h, dIA, dJA, nnzA, dIB, dJB, m, k, n, pre, dIC, &nnzC);
   if (rc) return cleanup(rc);
   if (hipSuccess != pool().alloc((void**)&dJC, sizeof(int) * (size_t)std::max(nnzC, 1)) ||
       hipSuccess != pool().alloc((void**)&dC, sizeof(float) * (size_t)std::max(nnzC, 1)))
     return cleanup(fail(SPGEMM_ERR_HIP, "device allocation of C (%d entries) failed", nnzC));
-  rc = numeric_phase(h, dIA, dJA, dA, dIB, dJB, dB, m, n, dIC, dJC, dC, nnzB);
+  rc = numeric_phase(h, dIA, dJA, dA, dIB, dJB, dB, m, n, dIC, dJC, dC);
   if (rc) return cleanup(rc);
   *dICp = dIC; *dJCp = dJC; *dCp = dC; *nnzCp = nnzC;
   return SPGEMM_OK;
@@ -854,7 +812,7 @@ extern "C" int hip_spgemm_symbolic(spgemm_handle* h, const int* dIA, const int* 
   CHK(check_common(dIB, dJB, dJB, nnzB, "B"));
   HIPCHK(hipSetDevice(h->device));
   CHK(ws_ensure(h, m));
-  return symbolic_phase(h, dIA, dJA, nnzA, dIB, dJB, m, k, n, nullptr, dIC, nnzC, nnzB);
+  return symbolic_phase(h, dIA, dJA, nnzA, dIB, dJB, m, k, n, nullptr, dIC, nnzC);
 }
 
 extern "C" int hip_spgemm_numeric(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, int nnzA,
@@ -866,7 +824,7 @@ extern "C" int hip_spgemm_numeric(spgemm_handle* h, const int* dIA, const int* d
   CHK(check_common(dIA, dJA, dA, nnzA, "A"));
   CHK(check_common(dIB, dJB, dB, nnzB, "B"));
   HIPCHK(hipSetDevice(h->device));
-  return numeric_phase(h, dIA, dJA, dA, dIB, dJB, dB, m, n, dIC, dJC, dC, nnzB);
+  return numeric_phase(h, dIA, dJA, dA, dIB, dJB, dB, m, n, dIC, dJC, dC);
 }
 
 extern "C" int hip_csr_row_flops(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, int m,
@@ -1329,7 +1287,6 @@ extern "C" int hip_rmcl_expand_prune(spgemm_handle* h, const int* dIA, const int
   h->cur_rowIds = h->rowIds;
   int rc = launch_classify(h, dIA, dJA, dIB, m, nnzA, dIC);
   if (rc) return cleanup(rc);
-  if ((rc = launch_pack(h, dJB, dB, nnzB))) return cleanup(rc);            // (experiment builds only)
   hipEventRecord(h->ev[1], s);
   if (hipMemcpyAsync(h->hmid, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
       hipEventRecord(h->evMid, s) != hipSuccess)
@@ -1356,13 +1313,8 @@ extern "C" int hip_rmcl_expand_prune(spgemm_handle* h, const int* dIA, const int
     if (nbig > 0) {
       KTimer t(h, SPGEMM_K_SYM_BIG, s);
       hipLaunchKernelGGL(k_sym_big, dim3(clampi(nbig, 1, h->numCU)), dim3(BIG_THREADS), sizeof(BigSymShared), s,
-                         h->dsmall->binPtr, 8, h->cur_rowIds, dIA, h->sbl,
-#ifdef SMF_PACKED_SYM
-                         reinterpret_cast<const int*>(h->packedB),
-#else
-                         dJB,
-#endif
-                         n, dIC, h->bigBitmaps, h->bm_cap, h->dsmall->qctr + 0 * 32);
+                         h->dsmall->binPtr, 8, h->cur_rowIds, dIA, h->sbl, dJB, n, dIC, h->bigBitmaps, h->bm_cap,
+                         h->dsmall->qctr + 0 * 32);
       if (hipGetLastError() != hipSuccess) return hipfail("symbolic launch");
     }
   } else if ((rc = launch_symbolic(h, dIA, dJB, m, n, h->cur_rowIds, dIC))) return cleanup(rc);
