@@ -209,6 +209,43 @@ void gpuRmclIter(const int maxIter, const CSR Mgt, CSR& Mt) {
   Mt.init(oA, oJ, oI, Mgt.rows, Mgt.cols, on);
 }
 
+static spgemm_group* make_group(int shards) {
+  int ndev = 0;
+  hip_or_die(spgemm_hip_device_count(&ndev), "spgemm_hip_device_count");
+  if (shards <= 0) shards = ndev;
+  std::vector<int> dev((size_t)shards);
+  for (int i = 0; i < shards; ++i) dev[(size_t)i] = i % (ndev > 0 ? ndev : 1);
+  spgemm_group* g = 0;
+  hip_or_die(spgemm_hip_group_create(&g, shards, dev.data(), SPGEMM_XCHG_AUTO), "spgemm_hip_group_create");
+  return g;
+}
+
+CSR gpuShardedSpMM(const CSR& hA, const CSR& hB, int shards) {
+  spgemm_group* g = make_group(shards);
+  spgemm_sharded* job = 0;
+  hip_or_die(hip_sharded_spmm_create(g, hA.rowPtr, hA.colInd, hA.values, hA.nnz, hB.rowPtr, hB.colInd, hB.values, hB.nnz,
+                                     hA.rows, hA.cols, hB.cols, &job), "hip_sharded_spmm_create");
+  long long nnzC = 0, P = 0;
+  hip_or_die(hip_sharded_spmm_step(job, 1, &nnzC, &P), "hip_sharded_spmm_step");
+  int *IC = 0, *JC = 0, nz = 0, rows = 0;
+  QValue* C = 0;
+  hip_or_die(hip_sharded_spmm_result(job, 0, &IC, &JC, &C, &nz, &rows), "hip_sharded_spmm_result");
+  hip_sharded_spmm_destroy(job);
+  spgemm_hip_group_destroy(g);
+  return CSR(C, JC, IC, rows, hB.cols, nz);       // malloc()ed like every host result: dispose() == free()
+}
+
+void gpuShardedRmclIter(const int maxIter, const CSR Mgt, CSR& Mt, int shards) {
+  spgemm_group* g = make_group(shards);
+  int *oI = 0, *oJ = 0, on = 0;
+  QValue* oA = 0;
+  hip_or_die(hip_gpuRmclIter_sharded(g, maxIter, Mt.rows, Mt.cols, Mgt.rowPtr, Mgt.colInd, Mgt.values, Mgt.nnz, Mt.rowPtr,
+                                     Mt.colInd, Mt.values, Mt.nnz, &oI, &oJ, &oA, &on), "gpuShardedRmclIter");
+  spgemm_hip_group_destroy(g);
+  Mt.dispose();
+  Mt.init(oA, oJ, oI, Mgt.rows, Mgt.cols, on);
+}
+
 void gpuOutputCSRWrapper(const CSR dA, const char* msg) {
   printf("%s\n", msg);
   printf("rows=%d cols=%d nnz=%d rowPtr=%p colInd=%p values=%p\n", dA.rows, dA.cols, dA.nnz, (void*)dA.rowPtr,

@@ -15,6 +15,13 @@ std::vector<int> gpuFlopsClassify(const CSR& dA, const CSR& dB, int** drowIdsp, 
 CSR sgpuSpMMWrapper(const CSR& dA, const CSR& dB, int* drowIds, const std::vector<int>& hv, int* dflops);
 CSR scudaSpMM(const CSR& hA, const CSR& hB);
 void gpuRmclIter(const int maxIter, const CSR Mgt, CSR& Mt);
+// Several GPUs (no counterpart in the reference, which is single-device: SURVEY.md section 2.4; the seam is the flops-balanced
+// row cut its CPU kernels make for their threads, nlibs/tools/util.cc:123-135).  HOST CSRs in, HOST CSR out: rows of A cut
+// into `shards` blocks of equal flops, one shard per device (shards > devices: logical shards share devices), B replicated,
+// the row segments of C gathered over RCCL / peer copies (include/spgemm_hip.h "multi-GPU").  shards <= 0: one per device.
+CSR gpuShardedSpMM(const CSR& hA, const CSR& hB, int shards = 0);
+// gpuRmclIter over an explicit number of shards (gpuRmclIter itself uses one per visible device)
+void gpuShardedRmclIter(const int maxIter, const CSR Mgt, CSR& Mt, int shards);
 // debug dump of a DEVICE CSR (nlibs/gpus/gpu_csr_kernel.h:7, .cu:15-42: message, shape and device pointers, the triples,
 // then the raw rowPtr and colInd/values arrays); the arrays are brought to the host and printed there
 void gpuOutputCSRWrapper(const CSR dA, const char* msg);

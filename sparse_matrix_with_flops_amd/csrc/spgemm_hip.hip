@@ -1393,10 +1393,14 @@ extern "C" int hip_gpuRmclIter(int maxIter, int rows, int cols, const int* gIA, 
       std::vector<int> devs((size_t)shards);
       for (int i = 0; i < shards; ++i) devs[(size_t)i] = i % std::max(use, 1);
       spgemm_group* grp = nullptr;
-      CHK(spgemm_hip_group_create(&grp, shards, devs.data(), SPGEMM_XCHG_AUTO));
-      const int rc = hip_gpuRmclIter_sharded(grp, maxIter, rows, cols, gIA, gJA, gA, gnnz, tIA, tJA, tA, tnnz, oIA, oJA, oA, onnz);
-      spgemm_hip_group_destroy(grp);
-      return rc;
+      int rc = spgemm_hip_group_create(&grp, shards, devs.data(), SPGEMM_XCHG_AUTO);
+      if (rc == SPGEMM_OK) {
+        rc = hip_gpuRmclIter_sharded(grp, maxIter, rows, cols, gIA, gJA, gA, gnnz, tIA, tJA, tA, tnnz, oIA, oJA, oA, onnz);
+        spgemm_hip_group_destroy(grp);
+      }
+      if (rc == SPGEMM_OK) return rc;
+      // the caller asked for an R-MCL result, not for a particular number of GPUs: say what went wrong and carry on with one
+      fprintf(stderr, "hip_gpuRmclIter: the %d-shard loop failed (%s); running on one device\n", shards, spgemm_hip_last_error());
     }
   }
   spgemm_handle* h = nullptr;

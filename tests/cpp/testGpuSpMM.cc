@@ -2,7 +2,8 @@
 // project's C++ mirror:  load -> toGpuCSR -> gpuSpMMWrapper -> toCpuCSR -> makeOrdered -> compare with the CPU
 // result.  The CPU result comes from the ORACLE (oracle/liboracle.so: test infrastructure, allowed here, never linked
 // into the product).  Also exercises hip_spmm (host in/out), scudaSpMM (classify + binned path) and, with
-// "--rmcl N", RMCL(file, N, GPU) vs the oracle's seqRmclIter restatement.
+// "--rmcl N", RMCL(file, N, GPU) vs the oracle's seqRmclIter restatement; the row-sharded forms (gpuShardedSpMM,
+// gpuShardedRmclIter) over 2-3 logical shards.
 //   usage: testGpuSpMM <file> [--rmcl N]        prints Same / Differs per check, exit code 0 iff all Same
 #include <cstdio>
 #include <cstdlib>
@@ -93,6 +94,14 @@ int main(int argc, char* argv[]) {
   h3.makeOrdered();
   bad += report("scudaSpMM parity", h3.isParityEqual(want));
   h3.dispose();
+  for (int shards = 2; shards <= 3; ++shards) {   // row-sharded over logical shards (every visible device takes its share)
+    CSR h4 = gpuShardedSpMM(A, B, shards);
+    h4.makeOrdered();
+    char what[64];
+    snprintf(what, sizeof what, "gpuShardedSpMM(%d) parity", shards);
+    bad += report(what, h4.rows == want.rows && h4.isParityEqual(want));
+    h4.dispose();
+  }
   printf("rows=%d nnzA=%d flops=%lld nnzC=%d\n", A.rows, A.nnz, A.spMMFlops(B), want.nnz);
   want.dispose(); A.dispose(); B.dispose();
 
@@ -108,6 +117,17 @@ int main(int argc, char* argv[]) {
     Mt.makeOrdered();
     ref.makeOrdered();
     bad += report("RMCL(GPU) vs SEQ isEqual", Mt.isEqual(ref));
+    {                                             // the same loop over two logical shards
+      COO c3;
+      c3.readSNAPFile(argv[1]);
+      CSR m2 = rmclInit(c3);
+      c3.dispose();
+      CSR g2 = m2.deepCopy();
+      gpuShardedRmclIter(rmclIters, g2, m2, 2);
+      m2.makeOrdered();
+      bad += report("gpuShardedRmclIter(2) isEqual", m2.isEqual(ref));
+      m2.dispose(); g2.dispose();
+    }
     Mt.dispose(); ref.dispose(); g.dispose();
   }
   return bad ? 1 : 0;
