@@ -171,6 +171,7 @@ extern "C" int hip_coo_to_csr(spgemm_handle* h, int rows, int cols, int nnz, con
   if ((flags & SPGEMM_COO_SELF_LOOPS) && rows != cols) return fail(SPGEMM_ERR_ARG, "self loops need a square matrix");
   if (!h) CHK(default_handle(&h));
   HIPCHK(hipSetDevice(h->device));
+  clear_stale_hip_error();
   hipStream_t s = h->stream;
   const int dedupe = (flags & SPGEMM_COO_DEDUPE) ? 1 : 0;
   const bool loops = (flags & SPGEMM_COO_SELF_LOOPS) != 0;
@@ -326,6 +327,7 @@ extern "C" int hip_flopsStats(spgemm_handle* h, const int* dIA, const int* dJA, 
   if (m == 0) return SPGEMM_OK;
   if (!h) CHK(default_handle(&h));
   HIPCHK(hipSetDevice(h->device));
+  clear_stale_hip_error();
   int *flops = nullptr, *hist = nullptr;
   auto cleanup = [&](int rc) { pool().release(flops); pool().release(hist); return rc; };
   if (pool().alloc((void**)&flops, sizeof(int) * (size_t)m) != hipSuccess ||
@@ -351,6 +353,7 @@ extern "C" int hip_nnzStats(spgemm_handle* h, const int* dIA, int m, int stats[S
   if (m == 0) return SPGEMM_OK;
   if (!h) CHK(default_handle(&h));
   HIPCHK(hipSetDevice(h->device));
+  clear_stale_hip_error();
   int* hist = nullptr;
   auto cleanup = [&](int rc) { pool().release(hist); return rc; };
   if (pool().alloc((void**)&hist, sizeof(int) * SPGEMM_NNZ_STATS_LEN) != hipSuccess) return cleanup(fail(SPGEMM_ERR_HIP, "device allocation failed"));

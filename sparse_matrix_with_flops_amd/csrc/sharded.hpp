@@ -118,6 +118,7 @@ static int group_init_comms(spgemm_group* g, const ncclUniqueId& id) {
     if (r != ncclSuccess) { R.GroupEnd(); return fail(SPGEMM_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", s.grank, g->nranks, R.GetErrorString(r)); }
   }
   NCCLCHK(R.GroupEnd());
+  clear_stale_hip_error();                         // (RCCL's device probing leaves errors in the thread's slot)
   return SPGEMM_OK;
 }
 
@@ -560,6 +561,7 @@ extern "C" int hip_sharded_spmm_step(spgemm_sharded* job, int gather, long long*
     CHK(numeric_phase(s.h, L.A.I, L.A.J, L.A.V, L.B.I, L.B.J, L.B.V, L.A.rows, job->n, L.lIC, L.gJ + off, L.gV + off));
     const int r0 = doGather ? job->ends[s.grank] : 0;
     const int cnt = L.A.rows + ((!doGather || s.grank == G - 1) ? 1 : 0);
+    clear_stale_hip_error();
     if (cnt > 0) hipLaunchKernelGGL(k_offset_copy, dim3(cdiv(cnt, 256)), dim3(256), 0, s.h->stream, cnt, L.lIC, (int)off, L.gI + r0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s.h->stream));
@@ -689,6 +691,7 @@ extern "C" int hip_gpuRmclIter_sharded(spgemm_group* g, int maxIter, int rows, i
       HIPCHK(pool().alloc((void**)&N.V, sizeof(float) * (size_t)std::max<long long>(total, 1)));
       const long long off = offs[(size_t)s.grank];
       const int cnt = L.Mg.rows + (s.grank == G - 1 ? 1 : 0);
+      clear_stale_hip_error();
       if (cnt > 0) hipLaunchKernelGGL(k_offset_copy, dim3(cdiv(cnt, 256)), dim3(256), 0, s.h->stream, cnt, L.pI, (int)off, N.I + ends[s.grank]);
       if (L.pn > 0) {
         HIPCHK(hipMemcpyAsync(N.J + off, L.pJ, sizeof(int) * (size_t)L.pn, hipMemcpyDeviceToDevice, s.h->stream));

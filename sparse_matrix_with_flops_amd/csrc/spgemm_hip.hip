@@ -382,6 +382,11 @@ extern "C" int spgemm_hip_memcpy_d2d(void* dst, const void* src, size_t bytes) {
 // ------------------------------------------------------------------------------------------------
 // launch sequence
 // ------------------------------------------------------------------------------------------------
+// hipGetLastError() after a batch of launches is how launch failures are noticed; the slot it reads is per thread and keeps
+// the last error of ANY earlier HIP call, ours or another library's in this process (RCCL probing devices leaves
+// "invalid device ordinal" behind: seen as a spurious failure of the next SpGEMM).  Every launch sequence therefore
+// starts by emptying the slot.
+static inline void clear_stale_hip_error() { (void)hipGetLastError(); }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline int clampi(long long v, int lo, int hi) { return (int)std::max<long long>(lo, std::min<long long>(v, hi)); }
 // grid of a statically scheduled kernel: a multiple of 8 (one contiguous eighth of the work per XCD: xcd_range)
@@ -447,6 +452,7 @@ static void join_streams(spgemm_handle* h) {
 // the C ABI that are not told nnz(A)): the sums gather through JA -> IB directly.
 static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, int m, long long nnzA, int* dIC) {
   const int nblk = cdiv(m, K1_THREADS);
+  clear_stale_hip_error();
   HIPCHK(hipMemsetAsync(h->dsmall, 0, sizeof(HostMirror), h->stream));
   if (nnzA >= 0) CHK(ws_ensure_entries(h, nnzA));
   if (m > 0) {
@@ -471,6 +477,7 @@ static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJB,
                            int m, int n, const int* rowIds, int* dIC) {
   const int2* sbl = h->sbl;
   if (m <= 0) return SPGEMM_OK;
+  clear_stale_hip_error();
   const int* bp = h->dsmall->binPtr;
   int* err = &h->dsmall->err;
   int* qc = h->dsmall->qctr;
@@ -506,6 +513,7 @@ static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJB,
 // exclusive scan of cnt[0..m) in place, cnt[m] = total; 64-bit total lands in *dTotal
 static int launch_scan(spgemm_handle* h, int* cnt, int m, unsigned long long* dTotal, bool clampTotal = true) {
   const int ntiles = std::max(1, cdiv(m, SCAN_TILE));
+  clear_stale_hip_error();
   KTimer t(h, SPGEMM_K_SCAN);
   hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(SCAN_THREADS), 0, h->stream, m, cnt, h->tileSum);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, h->stream, ntiles, h->tileSum, dTotal);
@@ -522,6 +530,7 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
   // pmode 2: no symbolic pass ran below bin 8: dIC holds the prefix sums of the rows' product counts there, exact counts
   // for the rows of bin 8
   const int2* sbl = h->sbl;
+  clear_stale_hip_error();
   const int* bp = h->dsmall->binPtr;
   int* err = &h->dsmall->err;
   int* qc = h->dsmall->qctr;
@@ -954,6 +963,7 @@ static int unpack_classification(spgemm_handle* h, int m, const PreClass& pre, i
   for (int b = 0; b < 8; ++b)
     if (hv[b] > hv[b + 1]) return fail(SPGEMM_ERR_ARG, "hv is not monotone");
   if (hv[8] != m + 1 || hv[1] != 0 || hv[2] < 1) return fail(SPGEMM_ERR_ARG, "hv does not describe %d rows", m);
+  clear_stale_hip_error();
   HIPCHK(hipMemsetAsync(h->dsmall, 0, sizeof(HostMirror), h->stream));
   if (m > 0) {
     int* n67 = h->dsmall->scratch2;
@@ -1189,6 +1199,7 @@ static int rmcl_prune_impl(spgemm_handle* h, int m, long long nnzIn, const int* 
   if (!h) CHK(default_handle(&h));
   HIPCHK(hipSetDevice(h->device));
   h->sym_m = -1;                                   // scan scratch and the small device block are shared with a pending phase
+  clear_stale_hip_error();
   CHK(ws_ensure(h, m));
   int* newPtr = nullptr; int* JN = nullptr; float* CN = nullptr; float* th = nullptr; float* ks = nullptr;
   auto cleanup = [&](int rc) { pool().release(newPtr); pool().release(JN); pool().release(CN); pool().release(th); pool().release(ks); return rc; };
@@ -1441,6 +1452,7 @@ extern "C" int hip_csr_sort_rows(spgemm_handle* h, int m, const int* dIC, int* d
   if (!h) CHK(default_handle(&h));
   HIPCHK(hipSetDevice(h->device));
   if (m == 0) return SPGEMM_OK;
+  clear_stale_hip_error();
   hipStream_t s = h->stream;
   int* dcnt = nullptr;
   int* JS = nullptr;
@@ -1481,6 +1493,7 @@ extern "C" int spgemm_hip_selftest(spgemm_handle* h) {
   HIPCHK(hipMalloc((void**)&dbad, sizeof(int)));
   HIPCHK(hipMemcpy(din, host.data(), sizeof(int) * host.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(dbad, 0, sizeof(int)));
+  clear_stale_hip_error();
   hipLaunchKernelGGL(k_selftest, dim3(nb), dim3(WAVE), 0, h->stream, din, dbad);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));

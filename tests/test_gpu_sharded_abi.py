@@ -170,3 +170,20 @@ def test_dist_module_calls_the_library_entry_points():
     nxt = library_rmcl(g, 1, host, host)
     assert_rmcl_step(po.CSRHost(nxt.rowPtr, nxt.colInd, nxt.values, Mt.rows, Mt.cols), Mt, Mt, what="library_rmcl, world 1")
     g.close()
+
+
+def test_a_stale_hip_error_of_another_library_does_not_fail_the_next_call():
+    """RCCL probes devices when a communicator is made and leaves "invalid device ordinal" in the thread's last-error slot;
+    the library checks that slot after its launch sequences.  Seen once as a spurious failure of the next hip_gpuSpMM
+    (test order dependent): every launch sequence now empties the slot first.  Make a communicator, then multiply."""
+    g = hs.Group(1, devices=[0], transport=hs.XCHG_RCCL)
+    A = synth_csr(5000, 3, 2)
+    dA = to_hs(A).toGpuCSR()
+    h = hs.Handle(0)
+    dC = hs.gpuSpMMWrapper(dA, dA, h)                  # failed with "hipGetLastError() failed: invalid device ordinal"
+    got = dC.toCpuCSR()
+    dC.deviceDispose()
+    dA.deviceDispose()
+    assert_parity(got, po.omp_spmm(A, A), what="SpGEMM right after RCCL initialisation")
+    h.close()
+    g.close()
