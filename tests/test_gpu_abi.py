@@ -59,10 +59,15 @@ def test_entry_points_complete_their_work_before_returning():
     first = c1.toCpuCSR()
     ptrs = (c1.rowPtr, c1.colInd, c1.values)
     c1.deviceDispose()
-    c2 = hs.gpuSpMMWrapper(dB, dB, h)               # same sizes class: the pool hands the freed blocks out again
-    assert {c2.rowPtr, c2.colInd, c2.values} & set(ptrs), "expected the cached blocks to be reused"
-    second = c2.toCpuCSR()
-    c2.deviceDispose()
+    freed = set(ptrs)
+    reused = False
+    for _ in range(3):                               # the pool hands freed blocks out again (best fit: which ones depends
+        c2 = hs.gpuSpMMWrapper(dB, dB, h)            # on what earlier tests left cached; the same request twice must reuse)
+        reused = reused or bool({c2.rowPtr, c2.colInd, c2.values} & freed)
+        second = c2.toCpuCSR()
+        freed |= {c2.rowPtr, c2.colInd, c2.values}
+        c2.deviceDispose()
+    assert reused, "expected cached blocks to be reused"
     from helpers import assert_parity
     assert_parity(first, po.omp_spmm(A, A), what="first product")
     assert_parity(second, po.omp_spmm(B, B), what="second product")
