@@ -81,6 +81,7 @@ int  spgemm_hip_free(void* dptr);
 /* bytes the caching allocator currently holds idle for `device` (tests; blocks are cached per device and given back
  * to the driver when the last handle of the device is destroyed) */
 int  spgemm_hip_pool_cached_bytes(int device, size_t* bytes);
+int  spgemm_hip_pool_trim(int device);            /* idle cached blocks of `device` go back to the driver now */
 int  spgemm_hip_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int  spgemm_hip_memcpy_d2h(void* dst, const void* src, size_t bytes);
 int  spgemm_hip_memcpy_d2d(void* dst, const void* src, size_t bytes);   /* device to device, same GPU */

@@ -358,6 +358,17 @@ extern "C" int spgemm_hip_pool_cached_bytes(int device, size_t* bytes) {
   *bytes = pool().cached_on(device);
   return SPGEMM_OK;
 }
+// give the idle cached blocks of `device` back to the driver (blocks in use are not touched)
+extern "C" int spgemm_hip_pool_trim(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return fail(SPGEMM_ERR_ARG, "device %d out of range", device);
+  int cur = 0;
+  const bool had = hipGetDevice(&cur) == hipSuccess;
+  HIPCHK(hipSetDevice(device));
+  pool().trim(device);
+  if (had) (void)hipSetDevice(cur);
+  return SPGEMM_OK;
+}
 extern "C" int spgemm_hip_free(void* dptr) {
   HIPCHK(pool().release(dptr));
   return SPGEMM_OK;

@@ -39,7 +39,7 @@ EXPORTS = [
     "spgemm_hip_group_create", "spgemm_hip_unique_id", "spgemm_hip_group_create_rank", "spgemm_hip_group_info",
     "spgemm_hip_group_destroy", "hip_sharded_spmm_create", "hip_sharded_spmm_step", "hip_sharded_spmm_result",
     "hip_sharded_spmm_info", "hip_sharded_spmm_destroy", "hip_gpuRmclIter_sharded", "spgemm_hip_host_api_stats",
-    "hip_sharded_spmm_handle", "spgemm_hip_rccl_available",
+    "hip_sharded_spmm_handle", "spgemm_hip_rccl_available", "spgemm_hip_pool_trim",
 ]
 XCHG_AUTO, XCHG_RCCL, XCHG_PEER, XCHG_HOST = 0, 1, 2, 3
 XCHG_NAMES = {0: "auto", 1: "rccl", 2: "peer", 3: "host"}
@@ -395,6 +395,11 @@ def rmcl_expand_prune_raw(handle, IA, JA, VA, nnzA, IB, JB, VB, nnzB, m, k, n):
                                        int(m), int(k), int(n), C.byref(i_), C.byref(j_), C.byref(c_), C.byref(n_)),
            "hip_rmcl_expand_prune")
     return i_.value, j_.value, c_.value, n_.value
+
+
+def pool_trim(device=0):
+    """idle cached blocks of the device go back to the driver"""
+    _check(lib().spgemm_hip_pool_trim(int(device)), "spgemm_hip_pool_trim")
 
 
 def pool_cached_bytes(device=0):

@@ -224,7 +224,10 @@ def test_compressive_product_is_not_held_at_twice_its_size():
     h = hs.Handle(0)
     dA = to_hs(A).toGpuCSR()
     from helpers import assert_parity
-    # call 0 is sized by P; its C stays alive, so that the later calls cannot be handed its (larger) blocks by the pool
+    # earlier tests leave idle blocks in the pool and it may hand out one up to 4x a request: start from an empty cache;
+    # call 0 is sized by P and its C stays alive, so that the later calls cannot be handed its (larger) blocks either
+    hs.pool_trim(0)
+    assert hs.pool_cached_bytes(0) == 0
     dC0 = hs.gpuSpMMWrapper(dA, dA, h)
     sizes = []
     for call in (1, 2):
