@@ -373,13 +373,35 @@ extern "C" int spgemm_hip_free(void* dptr) {
   HIPCHK(pool().release(dptr));
   return SPGEMM_OK;
 }
+// (copies of 8 MB and more between pageable host memory and the device go through the parallel pinned lanes further down:
+//  CSR::toGpuCSR / toCpuCSR of a large matrix then run at the link rate instead of the runtime's single staging thread)
+struct CopyJob { void* host; void* dev; size_t bytes; };
+static int copy_pageable(int dev, const CopyJob* jobs, int njobs, bool toDevice);
+static constexpr size_t kLaneCopyMin = size_t(8) << 20;
+static int device_of(const void* dptr) {           // the device a pointer lives on (the current one if the runtime cannot say)
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, dptr) == hipSuccess) return a.device;
+  (void)hipGetLastError();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev;
+}
+
 extern "C" int spgemm_hip_memcpy_h2d(void* dst, const void* src, size_t bytes) {
   if (bytes && (!dst || !src)) return fail(SPGEMM_ERR_ARG, "null pointer in h2d copy");
+  if (bytes >= kLaneCopyMin) {
+    const CopyJob j{const_cast<void*>(src), dst, bytes};
+    return copy_pageable(device_of(dst), &j, 1, true);
+  }
   if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
   return SPGEMM_OK;
 }
 extern "C" int spgemm_hip_memcpy_d2h(void* dst, const void* src, size_t bytes) {
   if (bytes && (!dst || !src)) return fail(SPGEMM_ERR_ARG, "null pointer in d2h copy");
+  if (bytes >= kLaneCopyMin) {
+    const CopyJob j{dst, const_cast<void*>(src), bytes};
+    return copy_pageable(device_of(src), &j, 1, false);
+  }
   if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return SPGEMM_OK;
 }
@@ -1093,7 +1115,6 @@ hipError_t lane_copy(int dev, hipStream_t st, char* const slots[2], char* host, 
 }  // namespace
 
 // several (host, device, bytes) pairs in one go: the bytes of all of them are dealt to the lanes in 4 MB chunks
-struct CopyJob { void* host; void* dev; size_t bytes; };
 static int copy_pageable(int dev, const CopyJob* jobs, int njobs, bool toDevice) {
   size_t total = 0;
   for (int i = 0; i < njobs; ++i) total += jobs[i].bytes;
@@ -1106,7 +1127,14 @@ static int copy_pageable(int dev, const CopyJob* jobs, int njobs, bool toDevice)
   }
   CopyLanes& L = lanes();
   std::lock_guard<std::mutex> lk(L.mu);
-  CHK(L.ensure(dev));
+  {
+    int cur = dev;                                       // the lanes' streams belong to `dev`: make them there
+    (void)hipGetDevice(&cur);
+    HIPCHK(hipSetDevice(dev));
+    const int rc = L.ensure(dev);
+    if (cur != dev) (void)hipSetDevice(cur);
+    CHK(rc);
+  }
   // cut every job into T slices (all lanes work on the same job at the same time: neighbouring pages, one job after the other)
   hipError_t errs[CopyLanes::T];
   std::vector<std::thread> th;
