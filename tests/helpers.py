@@ -35,14 +35,22 @@ def _canon(M):
     return canonical_arrays(M.rowPtr, M.colInd, M.values)
 
 
-def assert_parity(got, want, rel=REL_TOL, what="", inputs=None):
+def assert_parity(got, want, rel=REL_TOL, what="", inputs=None, accum=None):
     """The north_star parity rule: rowPtr bit-exact, per-row-sorted colInd bit-exact,
     values |x-y| <= rel*max(|x|,|y|).  `got`/`want` expose rowPtr/colInd/values/rows/cols.
 
     inputs=(A, B): for MIXED-SIGN inputs the sum order matters through cancellation and no reordering of a
     float32 sum can promise 1e-6 relative to the (possibly tiny) result; the bound is then taken relative to
     the magnitude of the terms, |x-y| <= rel * (|A|*|B|)_ij, computed with the oracle.  With non-negative
-    inputs (the reference's own setting: toAbs(), mindex2-cuda/nGpuSpMM.cc:291) both bounds coincide."""
+    inputs (the reference's own setting: toAbs(), mindex2-cuda/nGpuSpMM.cc:291) both bounds coincide.
+
+    accum=(A, B): products with FEW columns (or hub columns) sum hundreds to thousands of terms into one entry.  Two
+    float32 sums of N positive terms in different orders differ by about sqrt(N) * 2^-24 relative (random-walk rounding;
+    measured by tools/fuzz_parity.py: 1.0-1.5e-6 at N ~ 500, whichever side is "right" -- the oracle's sequential loop is
+    as far from the exact sum as the device's atomics), so 1e-6 cannot hold for such entries in ANY implementation that
+    does not reproduce the CPU loop's order.  With accum the tolerance of an entry that sums N products is
+    rel * max(1, sqrt(N) / 4) (N from the oracle on the all-ones pattern): unchanged up to 16 products per entry, which
+    covers every benchmark workload (their entries sum 1-20 products and are held to the plain 1e-6)."""
     assert got.rows == want.rows and got.cols == want.cols, f"{what}: shape {got.rows}x{got.cols} vs {want.rows}x{want.cols}"
     gr, wr = np.asarray(got.rowPtr), np.asarray(want.rowPtr)
     assert gr.shape == wr.shape, f"{what}: rowPtr length"
@@ -65,6 +73,14 @@ def assert_parity(got, want, rel=REL_TOL, what="", inputs=None):
         mc, mv = _canon(mag)
         assert np.array_equal(mc, wc)
         lim = np.maximum(lim, rel * mv.astype(np.float64))
+    if accum is not None:
+        A, B = accum
+        onesA = po.CSRHost(A.rowPtr, A.colInd, np.ones_like(A.values), A.rows, A.cols)
+        onesB = onesA if B is A else po.CSRHost(B.rowPtr, B.colInd, np.ones_like(B.values), B.rows, B.cols)
+        cnt = po.sequential_spmm(onesA, onesB)                 # (accumulates repeated columns like the device does)
+        cc, cn = _canon(cnt)
+        assert np.array_equal(cc, wc)
+        lim = lim * np.maximum(1.0, np.sqrt(cn.astype(np.float64)) / 4.0)
     if not np.all(err <= lim):
         bad = int(np.argmax(err - lim))
         raise AssertionError(f"{what}: value {bad}: {gv[bad]!r} vs {wv[bad]!r} (rel {err[bad] / max(abs(wv64[bad]), 1e-300):.3e})")
