@@ -272,6 +272,21 @@ std::vector<int> CSR::nnzStats() const {
   return stats;
 }
 
+std::vector<int> CSR::differsStats(const CSR& B, const std::vector<QValue>& percents) const {
+  const size_t n = percents.size();
+  std::vector<int> counts(n + 4, 0);                 // [0..n-1] below percents[k], [n] the rest, [n+1] appeared, [n+2] both empty, [n+3] equal
+  for (int i = 0; i < rows; ++i) {
+    const int a = rowPtr[i + 1] - rowPtr[i], b = B.rowPtr[i + 1] - B.rowPtr[i];
+    if (a == 0) { ++counts[b > 0 ? n + 1 : n + 2]; continue; }
+    if (a == b) { ++counts[n + 3]; continue; }
+    const QValue change = (QValue)(b - a) / (QValue)a;
+    size_t k = 0;
+    while (k < n && !(change < percents[k])) ++k;
+    ++counts[k];
+  }
+  return counts;
+}
+
 std::vector<int> CSR::gpuNnzStats() const {
   std::vector<int> stats(SPGEMM_NNZ_STATS_LEN, 0);
   if (hip_nnzStats(NULL, rowPtr, rows, stats.data())) { printf("%s\n", spgemm_hip_last_error()); exit(EXIT_FAILURE); }

@@ -49,5 +49,9 @@ struct CSR {
   // (after toGpuCSR): hip_nnzStats
   std::vector<int> nnzStats() const;
   std::vector<int> gpuNnzStats() const;
+  // how the row lengths moved from *this to B (nlibs/CSR.cc:381-415; the drift report of the R-MCL loop under --stats):
+  // counts[k] = rows whose relative change (len_B - len_A) / len_A is below percents[k] (first such k), counts[n] = the
+  // rest, then three more: rows that appeared (0 -> >0), rows empty in both, rows unchanged.  n = percents.size().
+  std::vector<int> differsStats(const CSR& B, const std::vector<QValue>& percents) const;
 };
 #endif

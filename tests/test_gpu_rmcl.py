@@ -223,6 +223,36 @@ def test_cpp_mirror_runs_the_reference_test_protocol():
         assert "rmclOption= GPU" in out.stdout and "Same" in out.stdout and "Diffs" not in out.stdout
         if "--stats" in args:
             assert "Total sum =" in out.stdout
+    # --stats also writes the reference's per-iteration drift report, percent.stats (nlibs/qrmcl.cc:17-24,65-70): one line
+    # per iteration with CSR::differsStats(Mt -> new Mt); recomputed here from the oracle's iterations (tie-free fixture)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = subprocess.run([exe, "-i", os.path.join(DATA, "own_graph.snap"), "-m", "3", "-r", "GPU", "--stats"],
+                             capture_output=True, text=True, timeout=300, cwd=td)
+        assert out.returncode == 0, out.stdout + out.stderr
+        lines = open(os.path.join(td, "percent.stats")).read().splitlines()
+    Mt = po.load(os.path.join(DATA, "own_graph.snap"), isTrans=True, mode=1)
+    assert lines[0] == f"rows {Mt.rows}" and lines[1].startswith("percent\t") and len(lines) == 2 + 3
+    percents = np.array([float(x) for x in lines[1].split("\t")[1].split()], dtype=np.float32)
+    assert list(percents) == [-30, -20, -5, 0, 5, 20, 30, 100]
+    cur = Mt
+    for it in range(3):
+        nxt = po.rmcl_iters(Mt, cur, 1)
+        a, b = np.diff(cur.rowPtr).astype(np.int64), np.diff(nxt.rowPtr).astype(np.int64)
+        counts = np.zeros(len(percents) + 4, dtype=np.int64)
+        for ai, bi in zip(a, b):
+            if ai == 0:
+                counts[len(percents) + (1 if bi > 0 else 2)] += 1
+            elif ai == bi:
+                counts[len(percents) + 3] += 1
+            else:
+                ch = np.float32(bi - ai) / np.float32(ai)
+                k = int(np.argmax(ch < percents)) if np.any(ch < percents) else len(percents)
+                counts[k] += 1
+        head, body = lines[2 + it].split(":\t")
+        assert head.strip() == str(it) and [int(x) for x in body.split()] == counts.tolist(), (it, lines[2 + it], counts)
+        assert counts.sum() == Mt.rows
+        cur = nxt
 
 
 def test_fused_expand_prune_degenerate_shapes():
