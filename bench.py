@@ -108,10 +108,15 @@ def traffic_for(workload, kernel, path=None):
     """PMC-derived HBM bytes per launch of `kernel` (profiles/collect.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes of
     this same command), newest round first.  -> ({raw, fetch_x2}, source) or (None, None)."""
     cands = [path] if path else [os.path.join(ROOT, "profiles", f"r{r:02d}_{workload}_traffic.json") for r in (3, 2, 1)]
+    # one timer id of the library covers BOTH launches of a split bin (tables of two sizes): their traffic adds up
+    parts = {"k_num_hash<1,1024>": ("k_num_hash<1,512>", "k_num_hash<1,1024>"), "k_sym_hash<1,1024>": ("k_sym_hash<1,512>", "k_sym_hash<1,1024>"),
+             "k_num_hash<4,4096>": ("k_num_hash<4,2048>", "k_num_hash<4,4096>")}.get(kernel, (kernel,))
     for tj in cands:
         if tj and os.path.exists(tj):
-            k = json.load(open(tj)).get("kernels", {}).get(kernel)
-            if k:
+            ks = json.load(open(tj)).get("kernels", {})
+            found = [ks[p_] for p_ in parts if p_ in ks]
+            if found:
+                k = {f_: sum(x.get(f_, 0) for x in found) for f_ in ("hbm_bytes_raw", "hbm_bytes_fetch_x2")}
                 return ({"raw": k.get("hbm_bytes_raw"), "fetch_x2": k.get("hbm_bytes_fetch_x2")},
                         f"{os.path.relpath(tj, ROOT)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, collected "
                         "separately (not in this run)")
