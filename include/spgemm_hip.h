@@ -197,6 +197,15 @@ int hip_rmcl_expand_prune(spgemm_handle* h,
                           const int* dIB, const int* dJB, const float* dB, int nnzB,
                           int m, int k, int n,
                           int** dIN, int** dJN, float** dCN, int* nnzN);
+/* hip_gpuRmclIter_device: the loop of gpuRmclIter (nlibs/gpus/gpu_csr_kernel.cu:281-311) on DEVICE arrays: maxIter
+ * iterations Mt <- prune(Mgt * Mt) starting from (dtI, dtJ, dtA), which are not modified; the result is a packed device
+ * CSR (release with spgemm_hip_free).  Between iterations Mt is kept in the layout the fused epilogues write (every
+ * row's kept entries at the front of its scratch range, {start, kept} per row): only the last iteration packs.  Same
+ * results as maxIter calls of hip_rmcl_expand_prune.  hip_gpuRmclIter = upload + this + download.  h may be NULL. */
+int hip_gpuRmclIter_device(spgemm_handle* h, int maxIter, int rows, int cols,
+                           const int* dgI, const int* dgJ, const float* dgA, int gnnz,
+                           const int* dtI, const int* dtJ, const float* dtA, int tnnz,
+                           int** oI, int** oJ, float** oA, int* onnz);
 int hip_gpuRmclIter(int maxIter, int rows, int cols,
                     const int* gIA, const int* gJA, const float* gA, int gnnz,
                     const int* tIA, const int* tJA, const float* tA, int tnnz,

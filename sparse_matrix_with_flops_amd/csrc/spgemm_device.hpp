@@ -594,9 +594,11 @@ __device__ __forceinline__ unsigned long long wave_incl_add_u64(unsigned long lo
 // the two kernels are one), an inclusive scan of the 64 lengths, and every row takes the difference of the scan values
 // at its two ends (two cross-lane reads).  No per-lane walk of its own row (64 different lines per load) and no serial
 // finishing of long rows.  CHK chunks are in flight together (their JA -> IB chains are independent).
+// IBlen != nullptr: B is NOT packed -- row j is [IB[j], IB[j] + IBlen[j]) (the pruned matrix of the previous R-MCL
+// iteration, left where the epilogues wrote it: hip_gpuRmclIter_device).  Everything downstream reads the records.
 __global__ __launch_bounds__(K1_THREADS) void k_row_flops(
     int m, const int* __restrict__ IA, const int* __restrict__ JA, const int* __restrict__ IB,
-    int2* __restrict__ SBL, int sblCap,
+    const int* __restrict__ IBlen, int2* __restrict__ SBL, int sblCap,
     int* __restrict__ rowFlops, unsigned char* __restrict__ binId, int* __restrict__ blockHist,
     unsigned long long* __restrict__ blockP, int* __restrict__ IC) {
   __shared__ int hist[NSLOTS];
@@ -616,7 +618,10 @@ __global__ __launch_bounds__(K1_THREADS) void k_row_flops(
 #pragma unroll
     for (int i = 0; i < CHK; ++i) { const int p = c0 + i * WAVE + lane; j[i] = p < e ? JA[p] : -1; }
 #pragma unroll
-    for (int i = 0; i < CHK; ++i) be[i] = j[i] >= 0 ? make_int2(IB[j[i]], IB[j[i] + 1]) : make_int2(0, 0);
+    for (int i = 0; i < CHK; ++i) {
+      if (IBlen) { const int b0 = j[i] >= 0 ? IB[j[i]] : 0; be[i] = make_int2(b0, b0 + (j[i] >= 0 ? IBlen[j[i]] : 0)); }
+      else be[i] = j[i] >= 0 ? make_int2(IB[j[i]], IB[j[i] + 1]) : make_int2(0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < CHK; ++i) {
       const int cb = c0 + i * WAVE;                           // wave-uniform

@@ -483,14 +483,15 @@ static void join_streams(spgemm_handle* h) {
 // flops + bins: K1, K2, K3.  Also presets IC[row] for rows with 0 / 1 products.
 // nnzA >= 0: the per-entry records h->sbl are (re)built first and the row sums read them; nnzA < 0 (entry points of
 // the C ABI that are not told nnz(A)): the sums gather through JA -> IB directly.
-static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, int m, long long nnzA, int* dIC) {
+static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, int m, long long nnzA, int* dIC,
+                           const int* dIBlen = nullptr) {
   const int nblk = cdiv(m, K1_THREADS);
   clear_stale_hip_error();
   HIPCHK(hipMemsetAsync(h->dsmall, 0, sizeof(HostMirror), h->stream));
   if (nnzA >= 0) CHK(ws_ensure_entries(h, nnzA));
   if (m > 0) {
     { KTimer t(h, SPGEMM_K_ROW_FLOPS);           // also writes the per-entry records h->sbl when nnz(A) is known
-      hipLaunchKernelGGL(k_row_flops, dim3(nblk), dim3(K1_THREADS), 0, h->stream, m, dIA, dJA, dIB,
+      hipLaunchKernelGGL(k_row_flops, dim3(nblk), dim3(K1_THREADS), 0, h->stream, m, dIA, dJA, dIB, dIBlen,
                          nnzA >= 0 ? h->sbl : (int2*)nullptr, (int)std::max(nnzA, 0ll), h->rowFlops,
                          h->binId, h->blockHist, h->blockP, dIC); }
     { KTimer t(h, SPGEMM_K_BIN_SCAN);
@@ -1305,23 +1306,61 @@ extern "C" int hip_rmcl_prune_n(spgemm_handle* h, int m, int nnz, const int* dIC
 // (about a quarter of the product) to the front of the row's range of a scratch C; k_rmcl_move packs them.
 // What the reference's loop does in three steps (gpu SpGEMM, inflate+threshold kernels of dutil.cuh, thrust::remove;
 // gpu_csr_kernel.cu:218-270) and hip_gpuSpMM + hip_rmcl_prune do in two.
-extern "C" int hip_rmcl_expand_prune(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, int nnzA,
-                                     const int* dIB, const int* dJB, const float* dB, int nnzB, int m, int k, int n,
-                                     int** dIN, int** dJN, float** dCN, int* nnzN) {
-  if (!dIN || !dJN || !dCN || !nnzN) return fail(SPGEMM_ERR_ARG, "output pointer is null");
-  *dIN = nullptr; *dJN = nullptr; *dCN = nullptr; *nnzN = 0;
-  if (m < 0 || k < 0 || n < 0) return fail(SPGEMM_ERR_ARG, "negative dimension m=%d k=%d n=%d", m, k, n);
-  CHK(check_common(dIA, dJA, dA, nnzA, "A"));
-  CHK(check_common(dIB, dJB, dB, nnzB, "B"));
-  if (!h) CHK(default_handle(&h));
+// Rows that sit at [starts[r], starts[r] + len[r]) of (J, V) -- where the epilogues of the fused R-MCL step leave them --
+// packed into a CSR of their own: the scan of the lengths is the row pointer, k_rmcl_move copies the rows.
+static int rmcl_pack_rows(spgemm_handle* h, int m, const int* starts, const int* len, const int* J, const float* V,
+                          int** pI, int** pJ, float** pV, int* pn) {
+  *pI = nullptr; *pJ = nullptr; *pV = nullptr; *pn = 0;
+  hipStream_t s = h->stream;
+  int* I = nullptr; int* JN = nullptr; float* CN = nullptr;
+  auto bad = [&](int rc) { pool().release(I); pool().release(JN); pool().release(CN); return rc; };
+  if (hipSuccess != pool().alloc((void**)&I, sizeof(int) * ((size_t)m + 1))) return fail(SPGEMM_ERR_NOMEM, "device allocation failed");
+  unsigned long long total = 0;
+  int rc;
+  if (hipMemsetAsync(I, 0, sizeof(int) * ((size_t)m + 1), s) != hipSuccess ||
+      hipMemcpyAsync(I, len, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return bad(fail(SPGEMM_ERR_HIP, "pack: copy of the row lengths"));
+  if ((rc = launch_scan(h, I, m, &h->dsmall->kept64))) return bad(rc);
+  if (hipMemcpyAsync(&h->hsmall->kept64, &h->dsmall->kept64, sizeof(total), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return bad(fail(SPGEMM_ERR_HIP, "pack: scan of the row lengths"));
+  total = h->hsmall->kept64;
+  if (total > 0x7fffffffULL) return bad(fail(SPGEMM_ERR_OVERFLOW, "pack: %llu entries", total));
+  const int nz = (int)total;
+  if (hipSuccess != pool().alloc((void**)&JN, sizeof(int) * (size_t)std::max(nz, 1)) ||
+      hipSuccess != pool().alloc((void**)&CN, sizeof(float) * (size_t)std::max(nz, 1)))
+    return bad(fail(SPGEMM_ERR_NOMEM, "device allocation failed"));
+  if (nz > 0 && m > 0) {
+    hipLaunchKernelGGL(k_rmcl_move<16>, dim3(clampi(cdiv(m, 16), 1, h->numCU * 16)), dim3(256), 0, s, m, starts, I, J, V, JN, CN);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return bad(fail(SPGEMM_ERR_HIP, "pack: move"));
+  }
+  *pI = I; *pJ = JN; *pV = CN; *pn = nz;
+  return SPGEMM_OK;
+}
+
+// One R-MCL iteration (expansion with the row rule fused into the numeric epilogues) on device arrays.
+//   dIBlen != nullptr   B is NOT packed: row j is [dIB[j], dIB[j] + dIBlen[j]) of (dJB, dB); nnzB = the arrays' extent
+//   pack == false       the result is left where the epilogues wrote it: *dIN = the scratch row starts (m + 1 entries),
+//                       *dLenN = the kept entries per row, *dJN / *dCN = the scratch arrays, *nnzN = their extent (P).
+//                       The next iteration reads it as its unpacked B: no scan, no copy, no allocation of packed arrays.
+//                       (The paths that give up on the fused step return a packed result and *dLenN = nullptr.)
+static int rmcl_expand_prune_core(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, int nnzA,
+                                  const int* dIB, const int* dIBlen, const int* dJB, const float* dB, int nnzB, int m,
+                                  int k, int n, bool pack, int** dIN, int** dLenN, int** dJN, float** dCN, int* nnzN) {
+  *dIN = nullptr; *dLenN = nullptr; *dJN = nullptr; *dCN = nullptr; *nnzN = 0;
   HIPCHK(hipSetDevice(h->device));
   auto two_steps = [&]() {                           // no rows, no products, or a product too large for the scratch C
+    int *bI = nullptr, *bJ = nullptr, bn = nnzB;
+    float* bV = nullptr;
+    int rc = SPGEMM_OK;
+    if (dIBlen && (rc = rmcl_pack_rows(h, k, dIB, dIBlen, dJB, dB, &bI, &bJ, &bV, &bn))) return rc;
     int *cI = nullptr, *cJ = nullptr, cn = 0;
     float* cA = nullptr;
-    int rc = spgemm_device(h, dIA, dJA, dA, nnzA, dIB, dJB, dB, nnzB, m, k, n, nullptr, &cI, &cJ, &cA, &cn);
-    if (rc) return rc;
-    rc = rmcl_prune_impl(h, m, cn, cI, cJ, cA, dIN, dJN, dCN, nnzN);
+    rc = spgemm_device(h, dIA, dJA, dA, nnzA, dIBlen ? bI : dIB, dIBlen ? bJ : dJB, dIBlen ? bV : dB, bn, m, k, n, nullptr,
+                       &cI, &cJ, &cA, &cn);
+    if (!rc) rc = rmcl_prune_impl(h, m, cn, cI, cJ, cA, dIN, dJN, dCN, nnzN);
     pool().release(cI); pool().release(cJ); pool().release(cA);
+    pool().release(bI); pool().release(bJ); pool().release(bV);
     return rc;
   };
   if (m == 0) return two_steps();
@@ -1339,7 +1378,7 @@ extern "C" int hip_rmcl_expand_prune(spgemm_handle* h, const int* dIA, const int
   h->sym_m = -1;
   hipEventRecord(h->ev[0], s);
   h->cur_rowIds = h->rowIds;
-  int rc = launch_classify(h, dIA, dJA, dIB, m, nnzA, dIC);
+  int rc = launch_classify(h, dIA, dJA, dIB, m, nnzA, dIC, dIBlen);
   if (rc) return cleanup(rc);
   hipEventRecord(h->ev[1], s);
   if (hipMemcpyAsync(h->hmid, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -1382,7 +1421,7 @@ extern "C" int hip_rmcl_expand_prune(spgemm_handle* h, const int* dIA, const int
   h->mirror = mid;
   if ((rc = launch_numeric(h, dIA, dA, dJB, dB, n, h->cur_rowIds, mid.binPtr, dIC, dJC, dC, cnt, nosym ? 2 : 1))) return cleanup(rc);
   hipEventRecord(h->ev[5], s);
-  if ((rc = launch_scan(h, cnt, m, &h->dsmall->kept64))) return cleanup(rc);
+  if (pack && (rc = launch_scan(h, cnt, m, &h->dsmall->kept64))) return cleanup(rc);
   if (hipMemcpyAsync(h->hsmall, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
       hipStreamSynchronize(s) != hipSuccess)
     return hipfail("numeric phase");
@@ -1400,6 +1439,10 @@ extern "C" int hip_rmcl_expand_prune(spgemm_handle* h, const int* dIA, const int
   hipEventElapsedTime(&st.ms_total, h->ev[0], h->ev[5]);
   collect_kernel_times(h, true);
   grow_bitmaps(h, n);
+  if (!pack) {                                       // the rows stay where the epilogues wrote them
+    *dIN = dIC; *dLenN = cnt; *dJN = dJC; *dCN = dC; *nnzN = (int)P;
+    return SPGEMM_OK;
+  }
   const int nz = (int)hm.kept64;                     // <= nnz(C) <= P <= 2^30
   if (hipSuccess != pool().alloc((void**)&JN, sizeof(int) * (size_t)std::max(nz, 1)) ||
       hipSuccess != pool().alloc((void**)&CN, sizeof(float) * (size_t)std::max(nz, 1)))
@@ -1413,6 +1456,69 @@ extern "C" int hip_rmcl_expand_prune(spgemm_handle* h, const int* dIA, const int
   if (hipStreamSynchronize(s) != hipSuccess) return hipfail("move");
   pool().release(dIC); pool().release(dJC); pool().release(dC);
   *dIN = cnt; *dJN = JN; *dCN = CN; *nnzN = nz;
+  return SPGEMM_OK;
+}
+
+extern "C" int hip_rmcl_expand_prune(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, int nnzA,
+                                     const int* dIB, const int* dJB, const float* dB, int nnzB, int m, int k, int n,
+                                     int** dIN, int** dJN, float** dCN, int* nnzN) {
+  if (!dIN || !dJN || !dCN || !nnzN) return fail(SPGEMM_ERR_ARG, "output pointer is null");
+  *dIN = nullptr; *dJN = nullptr; *dCN = nullptr; *nnzN = 0;
+  if (m < 0 || k < 0 || n < 0) return fail(SPGEMM_ERR_ARG, "negative dimension m=%d k=%d n=%d", m, k, n);
+  CHK(check_common(dIA, dJA, dA, nnzA, "A"));
+  CHK(check_common(dIB, dJB, dB, nnzB, "B"));
+  if (!h) CHK(default_handle(&h));
+  int* len = nullptr;
+  return rmcl_expand_prune_core(h, dIA, dJA, dA, nnzA, dIB, nullptr, dJB, dB, nnzB, m, k, n, true, dIN, &len, dJN, dCN, nnzN);
+}
+
+// The R-MCL loop on device arrays (gpuRmclIter, gpus/gpu_csr_kernel.cu:15-40, without its two copies): maxIter iterations
+// Mt <- prune(Mgt * Mt) from (tI, tJ, tA), which are left alone; the result is a packed device CSR of the library's
+// pool.  Between iterations Mt is NOT packed: every epilogue leaves its kept entries at the front of the row's scratch
+// range and the next classification reads {start, kept} per row (k_row_flops' IBlen), so that only the last iteration
+// pays for the scan of the counts, the packed arrays and the copy into them.
+extern "C" int hip_gpuRmclIter_device(spgemm_handle* h, int maxIter, int rows, int cols, const int* dgI, const int* dgJ,
+                                      const float* dgA, int gnnz, const int* dtI, const int* dtJ, const float* dtA,
+                                      int tnnz, int** oI, int** oJ, float** oA, int* onnz) {
+  if (!oI || !oJ || !oA || !onnz) return fail(SPGEMM_ERR_ARG, "output pointer is null");
+  *oI = nullptr; *oJ = nullptr; *oA = nullptr; *onnz = 0;
+  if (rows < 0 || cols != rows || maxIter < 0) return fail(SPGEMM_ERR_ARG, "R-MCL needs a square matrix and maxIter >= 0");
+  CHK(check_common(dgI, dgJ, dgA, gnnz, "Mgt"));
+  CHK(check_common(dtI, dtJ, dtA, tnnz, "Mt"));
+  if (!h) CHK(default_handle(&h));
+  HIPCHK(hipSetDevice(h->device));
+  const bool keep_packed = getenv("SPGEMM_RMCL_PACK") != nullptr;       // A/B switch: pack after every iteration
+  const int *bI = dtI, *bLen = nullptr, *bJ = dtJ;
+  const float* bV = dtA;
+  int bn = tnnz;
+  int *cI = nullptr, *cLen = nullptr, *cJ = nullptr;                    // the current Mt when the loop owns it
+  float* cV = nullptr;
+  auto drop = [&]() { pool().release(cI); pool().release(cLen); pool().release(cJ); pool().release(cV); cI = cLen = cJ = nullptr; cV = nullptr; };
+  for (int it = 0; it < maxIter; ++it) {
+    int *nI = nullptr, *nLen = nullptr, *nJ = nullptr, nn = 0;
+    float* nV = nullptr;
+    const bool pack = keep_packed || it == maxIter - 1;
+    const int rc = rmcl_expand_prune_core(h, dgI, dgJ, dgA, gnnz, bI, bLen, bJ, bV, bn, rows, cols, cols, pack, &nI, &nLen,
+                                          &nJ, &nV, &nn);
+    if (rc) { drop(); return rc; }
+    drop();
+    cI = nI; cLen = nLen; cJ = nJ; cV = nV;
+    bI = cI; bLen = cLen; bJ = cJ; bV = cV; bn = nn;
+  }
+  if (maxIter == 0) {                                // a copy of Mt
+    const size_t bi = sizeof(int) * ((size_t)rows + 1), bj = sizeof(int) * (size_t)std::max(tnnz, 1);
+    if (hipSuccess != pool().alloc((void**)&cI, bi) || hipSuccess != pool().alloc((void**)&cJ, bj) ||
+        hipSuccess != pool().alloc((void**)&cV, bj)) { drop(); return fail(SPGEMM_ERR_NOMEM, "device allocation failed"); }
+    if (hipMemcpyAsync(cI, dtI, bi, hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+        (tnnz > 0 && (hipMemcpyAsync(cJ, dtJ, sizeof(int) * (size_t)tnnz, hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+                      hipMemcpyAsync(cV, dtA, sizeof(float) * (size_t)tnnz, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)) ||
+        hipStreamSynchronize(h->stream) != hipSuccess) { drop(); return fail(SPGEMM_ERR_HIP, "copy of Mt"); }
+    bn = tnnz;
+  } else if (bLen) {                                 // the last iteration gave up on the fused step?  it returns packed: not reached
+    drop();
+    return fail(SPGEMM_ERR_INTERNAL, "the last iteration returned an unpacked matrix");
+  }
+  *oI = cI; *oJ = cJ; *oA = cV; *onnz = bn;
   return SPGEMM_OK;
 }
 
@@ -1469,10 +1575,10 @@ extern "C" int hip_gpuRmclIter(int maxIter, int rows, int cols, const int* gIA, 
   UP(dtI, tIA, sizeof(int) * ((size_t)rows + 1)); UP(dtJ, tJA, sizeof(int) * (size_t)tnnz); UP(dtA, tA, sizeof(float) * (size_t)tnnz);
 #undef UP
   int curnnz = tnnz;
-  for (int it = 0; it < maxIter; ++it) {
+  {
     int *nI = nullptr, *nJ = nullptr, nn = 0;
     float* nA = nullptr;
-    if ((rc = hip_rmcl_expand_prune(h, dgI, dgJ, dgA, gnnz, dtI, dtJ, dtA, curnnz, rows, cols, cols, &nI, &nJ, &nA, &nn))) return cleanup(rc);
+    if ((rc = hip_gpuRmclIter_device(h, maxIter, rows, cols, dgI, dgJ, dgA, gnnz, dtI, dtJ, dtA, tnnz, &nI, &nJ, &nA, &nn))) return cleanup(rc);
     pool().release(dtI); pool().release(dtJ); pool().release(dtA);
     dtI = nI; dtJ = nJ; dtA = nA; curnnz = nn;
   }

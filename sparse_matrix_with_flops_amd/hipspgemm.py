@@ -35,7 +35,7 @@ EXPORTS = [
     "hip_gpuFlopsClassify", "hip_sgpuSpMM", "hip_csr_sort_rows", "spgemm_hip_selftest",
     "hip_spgemm_symbolic", "hip_spgemm_numeric", "hip_csr_row_flops", "spgemm_hip_kernel_name",
     "hip_rmcl_prune", "hip_gpuRmclIter", "hip_coo_to_csr", "hip_flopsStats", "spgemm_hip_set_kernel_timing",
-    "hip_rmcl_prune_n", "hip_rmcl_expand_prune", "spgemm_hip_pool_cached_bytes", "hip_nnzStats", "hip_resultsComparison",
+    "hip_rmcl_prune_n", "hip_rmcl_expand_prune", "hip_gpuRmclIter_device", "spgemm_hip_pool_cached_bytes", "hip_nnzStats", "hip_resultsComparison",
     "spgemm_hip_group_create", "spgemm_hip_unique_id", "spgemm_hip_group_create_rank", "spgemm_hip_group_info",
     "spgemm_hip_group_destroy", "hip_sharded_spmm_create", "hip_sharded_spmm_step", "hip_sharded_spmm_result",
     "hip_sharded_spmm_info", "hip_sharded_spmm_destroy", "hip_gpuRmclIter_sharded", "spgemm_hip_host_api_stats",
@@ -119,6 +119,8 @@ def lib():
         L.hip_rmcl_prune.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + \
             [C.POINTER(C.c_void_p)] * 3 + [_I]
         L.hip_rmcl_expand_prune.argtypes = [C.c_void_p] + dev_in + dev_in + [C.c_int, C.c_int, C.c_int] + \
+            [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(C.c_int)]
+        L.hip_gpuRmclIter_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + dev_in + dev_in + \
             [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(C.c_int)]
         L.hip_rmcl_prune_n.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + \
             [C.POINTER(C.c_void_p)] * 3 + [_I]
@@ -517,6 +519,25 @@ def scudaSpMM(hA, hB, handle=None):
         dA.deviceDispose()
         if dB is not dA:
             dB.deviceDispose()
+
+
+def rmcl_iter_device_raw(handle, maxIter, rows, cols, gI, gJ, gV, gnnz, tI, tJ, tV, tnnz):
+    """hip_gpuRmclIter_device on raw device pointers: maxIter iterations Mt <- prune(Mgt * Mt) without packing Mt between
+    them.  Returns (I, J, V, nnz) of the final Mt in pool arrays; release the three with dev_free."""
+    i_, j_, c_, n_ = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+    _check(lib().hip_gpuRmclIter_device(handle.ptr if handle else None, int(maxIter), int(rows), int(cols), C.c_void_p(gI),
+                                        C.c_void_p(gJ), C.c_void_p(gV), int(gnnz), C.c_void_p(tI), C.c_void_p(tJ),
+                                        C.c_void_p(tV), int(tnnz), C.byref(i_), C.byref(j_), C.byref(c_), C.byref(n_)),
+           "hip_gpuRmclIter_device")
+    return i_.value, j_.value, c_.value, n_.value
+
+
+def gpuRmclIter_device(maxIter, Mgt, Mt, handle=None):
+    """hip_gpuRmclIter_device on device CSRs: returns the new Mt as a device CSR (the inputs are left alone)."""
+    assert Mgt.on_device and Mt.on_device
+    i_, j_, c_, n_ = rmcl_iter_device_raw(handle, maxIter, Mgt.rows, Mgt.cols, Mgt.rowPtr, Mgt.colInd, Mgt.values, Mgt.nnz,
+                                          Mt.rowPtr, Mt.colInd, Mt.values, Mt.nnz)
+    return CSR(c_, j_, i_, Mt.rows, Mt.cols, n_, on_device=True)
 
 
 def gpuRmclIter(maxIter, Mgt, Mt):

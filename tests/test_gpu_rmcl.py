@@ -139,6 +139,60 @@ def test_fused_and_two_step_loops_agree(monkeypatch):
             assert_rmcl_step(nxt, Mt, cur, what=f"fused={fused} symbolic={sym} iteration {k + 1}")
 
 
+@pytest.mark.parametrize("hubs", [False, True])
+def test_device_loop_leaves_Mt_unpacked_between_iterations(hubs, monkeypatch):
+    """hip_gpuRmclIter_device: between iterations Mt stays where the epilogues wrote it ({start, kept} per row, read by
+    k_row_flops' IBlen) and only the last iteration packs.  k iterations in one call against the oracle's step from the
+    (k-1)-iteration result of another call; hubs: rows beyond 4096 products (symbolic kernel + in-place fix-up of their
+    scratch rows) take part.  SPGEMM_RMCL_PACK (pack after every iteration) gives the same matrices; zero iterations
+    return a copy of Mt."""
+    monkeypatch.delenv("SPGEMM_RMCL_PACK", raising=False)
+    monkeypatch.delenv("SPGEMM_RMCL_SYMBOLIC", raising=False)
+    if hubs:
+        rng = np.random.default_rng(8)
+        m = 6000
+        lens = rng.choice([0, 1, 2, 4, 8, 20, 60, 150, 400, 1500], size=m, p=[.03, .1, .15, .2, .2, .15, .1, .04, .02, .01])
+        M0 = _ragged(m, m, lens, 21)
+    else:
+        M0 = _graph(20000, 77)
+        m = M0.rows
+    h = hs.Handle(0)
+    dM = to_hs(M0).toGpuCSR()
+
+    def run(k):
+        d = hs.gpuRmclIter_device(k, dM, dM, h)
+        st = h.stats()
+        out = d.toCpuCSR()
+        d.deviceDispose()
+        return po.CSRHost(out.rowPtr, out.colInd, out.values, m, m), st
+
+    prev = M0
+    for k in (1, 2, 3):
+        cur, st = run(k)
+        if hubs and k == 1:
+            assert st["bin_rows"][8] > 0, st["bin_rows"]
+        # k > 1: `prev` comes from ANOTHER run than the state this call multiplied.  Two runs sum a long row in different
+        # orders (LDS atomics of several waves), so an entry of prev that sits on its row's threshold may be kept in one
+        # and dropped in the other; on the hub graph such an entry is ~1e-5 of its row's kept sum, which renormalises
+        # the row by that much and moves every threshold it feeds.  Hence the wider bounds there (a wrong row start or
+        # length -- what this test is after -- is off by orders of magnitude more).
+        loose = dict(rel=5e-5, tie_rel=5e-5) if hubs and k > 1 else {}
+        ndiff, ties, _ = assert_rmcl_step(cur, M0, prev, what=f"device loop, {k} iterations (hubs={hubs})", **loose)
+        prev = cur
+    monkeypatch.setenv("SPGEMM_RMCL_PACK", "1")
+    packed, _ = run(3)
+    monkeypatch.delenv("SPGEMM_RMCL_PACK")
+    two, _ = run(2)
+    assert_rmcl_step(packed, M0, two, what="device loop packing every iteration", **(dict(rel=5e-5, tie_rel=5e-5) if hubs else {}))
+    zero, _ = run(0)
+    assert np.array_equal(zero.rowPtr, M0.rowPtr) and np.array_equal(zero.colInd, M0.colInd) and np.array_equal(zero.values, M0.values)
+    # the inputs were not touched
+    back = dM.toCpuCSR()
+    assert np.array_equal(back.rowPtr, M0.rowPtr) and np.array_equal(back.colInd, M0.colInd) and np.array_equal(back.values, M0.values)
+    dM.deviceDispose()
+    h.close()
+
+
 def test_rmcl_synthetic_graph_three_iterations():
     """Power-law graph, 3 iterations, every step checked against the oracle from the device's own previous state: rows
     are identical (kept columns bit-exact, values 1e-6) except where an entry sits within 4 float32 ulps of the prune
