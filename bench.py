@@ -336,6 +336,15 @@ def bench_spgemm(ctx, args, wl):
         if not ctx.all_ok(runner is not None):
             runner = None
             fallback = fallback or "another rank could not create its group"
+        if runner is not None:                                            # and one whole step through its exchange
+            ok = True
+            try:
+                runner.step(not args.no_gather)
+            except Exception as e:                                        # noqa: BLE001
+                ok, fallback = False, f"first step: {type(e).__name__}: {e}"
+            if not ctx.all_ok(ok):
+                runner = None
+                fallback = fallback or "the first step failed on another rank"
     if runner is None:
         runner = TorchRunner(ctx, host, chunks)
 
