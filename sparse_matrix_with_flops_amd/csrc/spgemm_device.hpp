@@ -594,11 +594,12 @@ __device__ __forceinline__ unsigned long long wave_incl_add_u64(unsigned long lo
 // the two kernels are one), an inclusive scan of the 64 lengths, and every row takes the difference of the scan values
 // at its two ends (two cross-lane reads).  No per-lane walk of its own row (64 different lines per load) and no serial
 // finishing of long rows.  CHK chunks are in flight together (their JA -> IB chains are independent).
-// IBlen != nullptr: B is NOT packed -- row j is [IB[j], IB[j] + IBlen[j]) (the pruned matrix of the previous R-MCL
-// iteration, left where the epilogues wrote it: hip_gpuRmclIter_device).  Everything downstream reads the records.
+// IBse != nullptr: B is NOT packed -- row j is [IBse[j].x, IBse[j].y) (the pruned matrix of the previous R-MCL
+// iteration, left where the epilogues wrote it: hip_gpuRmclIter_device; k_zip_extents makes the pairs so that the
+// gather stays ONE 8-byte load per entry).  Everything downstream reads the records.
 __global__ __launch_bounds__(K1_THREADS) void k_row_flops(
     int m, const int* __restrict__ IA, const int* __restrict__ JA, const int* __restrict__ IB,
-    const int* __restrict__ IBlen, int2* __restrict__ SBL, int sblCap,
+    const int2* __restrict__ IBse, int2* __restrict__ SBL, int sblCap,
     int* __restrict__ rowFlops, unsigned char* __restrict__ binId, int* __restrict__ blockHist,
     unsigned long long* __restrict__ blockP, int* __restrict__ IC) {
   __shared__ int hist[NSLOTS];
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(K1_THREADS) void k_row_flops(
     for (int i = 0; i < CHK; ++i) { const int p = c0 + i * WAVE + lane; j[i] = p < e ? JA[p] : -1; }
 #pragma unroll
     for (int i = 0; i < CHK; ++i) {
-      if (IBlen) { const int b0 = j[i] >= 0 ? IB[j[i]] : 0; be[i] = make_int2(b0, b0 + (j[i] >= 0 ? IBlen[j[i]] : 0)); }
+      if (IBse) be[i] = j[i] >= 0 ? IBse[j[i]] : make_int2(0, 0);
       else be[i] = j[i] >= 0 ? make_int2(IB[j[i]], IB[j[i] + 1]) : make_int2(0, 0);
     }
 #pragma unroll
@@ -2166,6 +2167,13 @@ __global__ __launch_bounds__(256) void k_rmcl_compact(int m, const int* __restri
   }
 }
 
+
+// fused path, loop form: {start, end} of every row's kept entries in the scratch arrays, one pair per row
+__global__ __launch_bounds__(256) void k_zip_extents(int m, const int* __restrict__ IC, const int* __restrict__ cnt,
+                                                      int2* __restrict__ se) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < m) { const int s = IC[r]; se[r] = make_int2(s, s + cnt[r]); }
+}
 
 // fused path, after the numeric kernels: the kept entries sit at the front of every row's scratch range
 // [IC[row], ...), newPtr is the scan of their counts -- pack them into the new arrays

@@ -484,14 +484,14 @@ static void join_streams(spgemm_handle* h) {
 // nnzA >= 0: the per-entry records h->sbl are (re)built first and the row sums read them; nnzA < 0 (entry points of
 // the C ABI that are not told nnz(A)): the sums gather through JA -> IB directly.
 static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, const int* dIB, int m, long long nnzA, int* dIC,
-                           const int* dIBlen = nullptr) {
+                           const int2* dIBse = nullptr) {
   const int nblk = cdiv(m, K1_THREADS);
   clear_stale_hip_error();
   HIPCHK(hipMemsetAsync(h->dsmall, 0, sizeof(HostMirror), h->stream));
   if (nnzA >= 0) CHK(ws_ensure_entries(h, nnzA));
   if (m > 0) {
     { KTimer t(h, SPGEMM_K_ROW_FLOPS);           // also writes the per-entry records h->sbl when nnz(A) is known
-      hipLaunchKernelGGL(k_row_flops, dim3(nblk), dim3(K1_THREADS), 0, h->stream, m, dIA, dJA, dIB, dIBlen,
+      hipLaunchKernelGGL(k_row_flops, dim3(nblk), dim3(K1_THREADS), 0, h->stream, m, dIA, dJA, dIB, dIBse,
                          nnzA >= 0 ? h->sbl : (int2*)nullptr, (int)std::max(nnzA, 0ll), h->rowFlops,
                          h->binId, h->blockHist, h->blockP, dIC); }
     { KTimer t(h, SPGEMM_K_BIN_SCAN);
@@ -1339,15 +1339,18 @@ static int rmcl_pack_rows(spgemm_handle* h, int m, const int* starts, const int*
 }
 
 // One R-MCL iteration (expansion with the row rule fused into the numeric epilogues) on device arrays.
-//   dIBlen != nullptr   B is NOT packed: row j is [dIB[j], dIB[j] + dIBlen[j]) of (dJB, dB); nnzB = the arrays' extent
+//   dIBlen != nullptr   B is NOT packed: row j is [dIB[j], dIB[j] + dIBlen[j]) of (dJB, dB), dIBse[j] holds the same
+//                       extent as one {start, end} pair (what the classification gathers); nnzB = the arrays' extent
 //   pack == false       the result is left where the epilogues wrote it: *dIN = the scratch row starts (m + 1 entries),
-//                       *dLenN = the kept entries per row, *dJN / *dCN = the scratch arrays, *nnzN = their extent (P).
+//                       *dLenN = the kept entries per row, *dSEN = the {start, end} pairs, *dJN / *dCN = the scratch
+//                       arrays, *nnzN = their extent (P).
 //                       The next iteration reads it as its unpacked B: no scan, no copy, no allocation of packed arrays.
 //                       (The paths that give up on the fused step return a packed result and *dLenN = nullptr.)
 static int rmcl_expand_prune_core(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, int nnzA,
-                                  const int* dIB, const int* dIBlen, const int* dJB, const float* dB, int nnzB, int m,
-                                  int k, int n, bool pack, int** dIN, int** dLenN, int** dJN, float** dCN, int* nnzN) {
-  *dIN = nullptr; *dLenN = nullptr; *dJN = nullptr; *dCN = nullptr; *nnzN = 0;
+                                  const int* dIB, const int* dIBlen, const int2* dIBse, const int* dJB, const float* dB,
+                                  int nnzB, int m, int k, int n, bool pack, int** dIN, int** dLenN, int2** dSEN,
+                                  int** dJN, float** dCN, int* nnzN) {
+  *dIN = nullptr; *dLenN = nullptr; *dSEN = nullptr; *dJN = nullptr; *dCN = nullptr; *nnzN = 0;
   HIPCHK(hipSetDevice(h->device));
   auto two_steps = [&]() {                           // no rows, no products, or a product too large for the scratch C
     int *bI = nullptr, *bJ = nullptr, bn = nnzB;
@@ -1378,7 +1381,7 @@ static int rmcl_expand_prune_core(spgemm_handle* h, const int* dIA, const int* d
   h->sym_m = -1;
   hipEventRecord(h->ev[0], s);
   h->cur_rowIds = h->rowIds;
-  int rc = launch_classify(h, dIA, dJA, dIB, m, nnzA, dIC, dIBlen);
+  int rc = launch_classify(h, dIA, dJA, dIB, m, nnzA, dIC, dIBse);
   if (rc) return cleanup(rc);
   hipEventRecord(h->ev[1], s);
   if (hipMemcpyAsync(h->hmid, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -1440,8 +1443,12 @@ static int rmcl_expand_prune_core(spgemm_handle* h, const int* dIA, const int* d
   collect_kernel_times(h, true);
   grow_bitmaps(h, n);
   if (!pack) {                                       // the rows stay where the epilogues wrote them
-    *dIN = dIC; *dLenN = cnt; *dJN = dJC; *dCN = dC; *nnzN = (int)P;
-    return SPGEMM_OK;
+    int2* se = nullptr;
+    if (hipSuccess != pool().alloc((void**)&se, sizeof(int2) * (size_t)m)) return hipfail("device allocation failed");
+    hipLaunchKernelGGL(k_zip_extents, dim3(cdiv(m, 256)), dim3(256), 0, s, m, dIC, cnt, se);
+    if (hipGetLastError() != hipSuccess) { pool().release(se); return hipfail("extent launch"); }
+    *dIN = dIC; *dLenN = cnt; *dSEN = se; *dJN = dJC; *dCN = dC; *nnzN = (int)P;
+    return SPGEMM_OK;                                // stream order: the next classification runs behind the kernel
   }
   const int nz = (int)hm.kept64;                     // <= nnz(C) <= P <= 2^30
   if (hipSuccess != pool().alloc((void**)&JN, sizeof(int) * (size_t)std::max(nz, 1)) ||
@@ -1469,7 +1476,9 @@ extern "C" int hip_rmcl_expand_prune(spgemm_handle* h, const int* dIA, const int
   CHK(check_common(dIB, dJB, dB, nnzB, "B"));
   if (!h) CHK(default_handle(&h));
   int* len = nullptr;
-  return rmcl_expand_prune_core(h, dIA, dJA, dA, nnzA, dIB, nullptr, dJB, dB, nnzB, m, k, n, true, dIN, &len, dJN, dCN, nnzN);
+  int2* se = nullptr;
+  return rmcl_expand_prune_core(h, dIA, dJA, dA, nnzA, dIB, nullptr, nullptr, dJB, dB, nnzB, m, k, n, true, dIN, &len, &se,
+                                dJN, dCN, nnzN);
 }
 
 // The R-MCL loop on device arrays (gpuRmclIter, gpus/gpu_csr_kernel.cu:15-40, without its two copies): maxIter iterations
@@ -1489,21 +1498,27 @@ extern "C" int hip_gpuRmclIter_device(spgemm_handle* h, int maxIter, int rows, i
   HIPCHK(hipSetDevice(h->device));
   const bool keep_packed = getenv("SPGEMM_RMCL_PACK") != nullptr;       // A/B switch: pack after every iteration
   const int *bI = dtI, *bLen = nullptr, *bJ = dtJ;
+  const int2* bSE = nullptr;
   const float* bV = dtA;
   int bn = tnnz;
   int *cI = nullptr, *cLen = nullptr, *cJ = nullptr;                    // the current Mt when the loop owns it
+  int2* cSE = nullptr;
   float* cV = nullptr;
-  auto drop = [&]() { pool().release(cI); pool().release(cLen); pool().release(cJ); pool().release(cV); cI = cLen = cJ = nullptr; cV = nullptr; };
+  auto drop = [&]() {
+    for (void* q : {(void*)cI, (void*)cLen, (void*)cSE, (void*)cJ, (void*)cV}) pool().release(q);
+    cI = cLen = cJ = nullptr; cSE = nullptr; cV = nullptr;
+  };
   for (int it = 0; it < maxIter; ++it) {
     int *nI = nullptr, *nLen = nullptr, *nJ = nullptr, nn = 0;
+    int2* nSE = nullptr;
     float* nV = nullptr;
     const bool pack = keep_packed || it == maxIter - 1;
-    const int rc = rmcl_expand_prune_core(h, dgI, dgJ, dgA, gnnz, bI, bLen, bJ, bV, bn, rows, cols, cols, pack, &nI, &nLen,
-                                          &nJ, &nV, &nn);
+    const int rc = rmcl_expand_prune_core(h, dgI, dgJ, dgA, gnnz, bI, bLen, bSE, bJ, bV, bn, rows, cols, cols, pack, &nI,
+                                          &nLen, &nSE, &nJ, &nV, &nn);
     if (rc) { drop(); return rc; }
     drop();
-    cI = nI; cLen = nLen; cJ = nJ; cV = nV;
-    bI = cI; bLen = cLen; bJ = cJ; bV = cV; bn = nn;
+    cI = nI; cLen = nLen; cSE = nSE; cJ = nJ; cV = nV;
+    bI = cI; bLen = cLen; bSE = cSE; bJ = cJ; bV = cV; bn = nn;
   }
   if (maxIter == 0) {                                // a copy of Mt
     const size_t bi = sizeof(int) * ((size_t)rows + 1), bj = sizeof(int) * (size_t)std::max(tnnz, 1);
