@@ -594,9 +594,10 @@ __device__ __forceinline__ unsigned long long wave_incl_add_u64(unsigned long lo
 // the two kernels are one), an inclusive scan of the 64 lengths, and every row takes the difference of the scan values
 // at its two ends (two cross-lane reads).  No per-lane walk of its own row (64 different lines per load) and no serial
 // finishing of long rows.  CHK chunks are in flight together (their JA -> IB chains are independent).
-// IBse != nullptr: B is NOT packed -- row j is [IBse[j].x, IBse[j].y) (the pruned matrix of the previous R-MCL
+// EXTENTS: B is NOT packed -- row j is [IBse[j].x, IBse[j].y) (the pruned matrix of the previous R-MCL
 // iteration, left where the epilogues wrote it: hip_gpuRmclIter_device; k_zip_extents makes the pairs so that the
 // gather stays ONE 8-byte load per entry).  Everything downstream reads the records.
+template <bool EXTENTS>
 __global__ __launch_bounds__(K1_THREADS) void k_row_flops(
     int m, const int* __restrict__ IA, const int* __restrict__ JA, const int* __restrict__ IB,
     const int2* __restrict__ IBse, int2* __restrict__ SBL, int sblCap,
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(K1_THREADS) void k_row_flops(
     for (int i = 0; i < CHK; ++i) { const int p = c0 + i * WAVE + lane; j[i] = p < e ? JA[p] : -1; }
 #pragma unroll
     for (int i = 0; i < CHK; ++i) {
-      if (IBse) be[i] = j[i] >= 0 ? IBse[j[i]] : make_int2(0, 0);
+      if (EXTENTS) be[i] = j[i] >= 0 ? IBse[j[i]] : make_int2(0, 0);
       else be[i] = j[i] >= 0 ? make_int2(IB[j[i]], IB[j[i] + 1]) : make_int2(0, 0);
     }
 #pragma unroll

@@ -491,9 +491,12 @@ static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, con
   if (nnzA >= 0) CHK(ws_ensure_entries(h, nnzA));
   if (m > 0) {
     { KTimer t(h, SPGEMM_K_ROW_FLOPS);           // also writes the per-entry records h->sbl when nnz(A) is known
-      hipLaunchKernelGGL(k_row_flops, dim3(nblk), dim3(K1_THREADS), 0, h->stream, m, dIA, dJA, dIB, dIBse,
-                         nnzA >= 0 ? h->sbl : (int2*)nullptr, (int)std::max(nnzA, 0ll), h->rowFlops,
-                         h->binId, h->blockHist, h->blockP, dIC); }
+      int2* const sbl = nnzA >= 0 ? h->sbl : (int2*)nullptr;
+      const int cap = (int)std::max(nnzA, 0ll);
+      if (dIBse) hipLaunchKernelGGL(k_row_flops<true>, dim3(nblk), dim3(K1_THREADS), 0, h->stream, m, dIA, dJA, dIB, dIBse,
+                                    sbl, cap, h->rowFlops, h->binId, h->blockHist, h->blockP, dIC);
+      else hipLaunchKernelGGL(k_row_flops<false>, dim3(nblk), dim3(K1_THREADS), 0, h->stream, m, dIA, dJA, dIB, dIBse,
+                              sbl, cap, h->rowFlops, h->binId, h->blockHist, h->blockP, dIC); }
     { KTimer t(h, SPGEMM_K_BIN_SCAN);
       hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, h->stream, nblk, h->blockHist, h->blockOff,
                          h->dsmall->binPtr, h->dsmall->slotBase, h->blockP, &h->dsmall->totalP); }
