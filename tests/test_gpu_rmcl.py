@@ -347,6 +347,28 @@ def test_fused_expand_prune_degenerate_shapes():
     assert_rmcl_step(got, Ah, Ih, what="1x3 row")
 
 
+def test_device_loop_degenerate_inputs_and_argument_errors():
+    """hip_gpuRmclIter_device where the fused step gives up (a matrix with no entries: every iteration takes the two-step
+    path and returns a packed, empty Mt; a 1x1 graph), and its argument checks (non-square, negative iteration count)."""
+    empty = hs.CSR.from_arrays(np.zeros(6, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32), 5, 5).toGpuCSR()
+    out = hs.gpuRmclIter_device(3, empty, empty)
+    host = out.toCpuCSR()
+    assert host.nnz == 0 and host.rowPtr.tolist() == [0] * 6
+    out.deviceDispose()
+    one = hs.CSR.from_arrays(np.array([0, 1], np.int32), np.zeros(1, np.int32), np.array([0.5], np.float32), 1, 1).toGpuCSR()
+    out = hs.gpuRmclIter_device(4, one, one)
+    host = out.toCpuCSR()
+    assert host.rowPtr.tolist() == [0, 1] and host.colInd.tolist() == [0] and abs(float(host.values[0]) - 1.0) < 1e-6
+    out.deviceDispose()
+    with pytest.raises(hs.SpgemmError):
+        hs.gpuRmclIter_device(-1, one, one)
+    rect = hs.CSR.from_arrays(np.array([0, 1], np.int32), np.zeros(1, np.int32), np.array([0.5], np.float32), 1, 3).toGpuCSR()
+    with pytest.raises(hs.SpgemmError):
+        hs.gpuRmclIter_device(1, rect, rect)
+    for d in (empty, one, rect):
+        d.deviceDispose()
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_fused_expand_prune_random_rectangular(seed):
     """Random rectangular A (m x k) and B (k x n) with unsorted rows and non-negative values (what R-MCL multiplies;
