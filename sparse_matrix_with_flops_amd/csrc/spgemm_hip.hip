@@ -1394,7 +1394,11 @@ static int rmcl_expand_prune_core(spgemm_handle* h, const int* dIA, const int* d
   if (hipEventSynchronize(h->evMid) != hipSuccess) return hipfail("classification");
   const HostMirror mid = *h->hmid;
   const unsigned long long P = mid.totalP;
-  if (P == 0 || P > (1ull << 30)) {
+  // products beyond which the scratch C (8 bytes per product) is not made and the step runs as SpGEMM + prune.
+  // SPGEMM_RMCL_MAXP lowers the bound (test hook: the give-up path behind an unpacked Mt on small inputs).
+  unsigned long long maxP = 1ull << 30;
+  if (const char* e = getenv("SPGEMM_RMCL_MAXP")) maxP = std::min<unsigned long long>(maxP, strtoull(e, nullptr, 10));
+  if (P == 0 || P > maxP) {
     if (hipStreamSynchronize(s) != hipSuccess) return hipfail("classification");
     cleanup(0);
     dIC = cnt = dJC = JN = nullptr; dC = CN = nullptr;

@@ -347,6 +347,37 @@ def test_fused_expand_prune_degenerate_shapes():
     assert_rmcl_step(got, Ah, Ih, what="1x3 row")
 
 
+def test_device_loop_gives_up_on_the_fused_step_behind_an_unpacked_Mt(monkeypatch):
+    """Iteration 1 runs fused and leaves Mt unpacked; iteration 2 has more products than the scratch bound allows
+    (SPGEMM_RMCL_MAXP, a test hook for the 2^30 bound) and runs as SpGEMM + prune: the unpacked Mt is packed first
+    (rmcl_pack_rows).  Iteration 3 is above the bound too and stays on that path, now with a packed Mt."""
+    monkeypatch.delenv("SPGEMM_RMCL_PACK", raising=False)
+    M0 = _graph(20000, 77)
+    m = M0.rows
+    dM = to_hs(M0).toGpuCSR()
+    h = hs.Handle(0)
+
+    def run(k):
+        d = hs.gpuRmclIter_device(k, dM, dM, h)
+        out = d.toCpuCSR()
+        d.deviceDispose()
+        return po.CSRHost(out.rowPtr, out.colInd, out.values, m, m)
+
+    M1 = run(1)
+    P1 = int(po.row_flops(M0, M0).sum())
+    P2 = int(po.row_flops(M0, M1).sum())
+    assert P2 > P1                                                        # the products grow from iteration 1 to 2
+    monkeypatch.setenv("SPGEMM_RMCL_MAXP", str((P1 + P2) // 2))
+    M2 = run(2)
+    assert h.stats()["nnzC"] >= 0                                         # the last step counted its product: SpGEMM + prune ran
+    assert_rmcl_step(M2, M0, M1, what="iteration 2 on the two-step path behind an unpacked Mt")
+    M3 = run(3)
+    assert_rmcl_step(M3, M0, M2, what="iteration 3")
+    monkeypatch.delenv("SPGEMM_RMCL_MAXP")
+    dM.deviceDispose()
+    h.close()
+
+
 def test_device_loop_degenerate_inputs_and_argument_errors():
     """hip_gpuRmclIter_device where the fused step gives up (a matrix with no entries: every iteration takes the two-step
     path and returns a packed, empty Mt; a 1x1 graph), and its argument checks (non-square, negative iteration count)."""
