@@ -611,6 +611,16 @@ def bench_rmcl(ctx, args, wl):
     last.deviceDispose()
     start.deviceDispose()
     G_.deviceDispose()
+    # the call the reference's driver makes: host CSRs in, host CSR out (upload + the loop above + download), never `value`
+    host_api = None
+    if not args.no_host_api:
+        hs.gpuRmclIter(iters, H, H)
+        t2 = time.perf_counter()
+        nh = 3
+        for _ in range(nh):
+            R_ = hs.gpuRmclIter(iters, H, H)
+        host_api = {"entry": "hip_gpuRmclIter (gpuRmclIter, nlibs/gpus/gpu_csr_kernel.cu:281-311): host arrays in and out",
+                    "ms": round((time.perf_counter() - t2) * 1e3 / nh, 3), "final_nnz": int(R_.nnz)}
 
     # algorithmic bytes of one fused iteration: read A (= Mgt) and the gathered B entries, write only what survives the prune
     nnzA = int(Mt.nnz)
@@ -630,6 +640,7 @@ def bench_rmcl(ctx, args, wl):
         "config": {"workload": wl["desc"], "name": args.workload, "m": m, "nnz_Mt0": nnzA, "iterations": iters,
                    "products_per_step": P_total, "parallelism": "single GPU"},
         "loop_one_call_per_iteration_ms": round(per_call_ms, 3),
+        "host_api": host_api,
         "per_iteration": [{"P": p_["P"], "nnz_in": p_["nnz_in"], "kept": p_["kept"], "ms": round(p_["ms"], 3),
                            "alg_GBs": round(b_ / (p_["ms"] * 1e-3) / 1e9, 1)} for p_, b_ in zip(per, it_bytes)],
         "pipeline_bytes_alg_GBs": round(sum(it_bytes) / (ms_per_step * 1e-3) / 1e9, 2),
