@@ -187,3 +187,89 @@ def test_a_stale_hip_error_of_another_library_does_not_fail_the_next_call():
     assert_parity(got, po.omp_spmm(A, A), what="SpGEMM right after RCCL initialisation")
     h.close()
     g.close()
+
+
+_LOOPBACK_SCRIPT = r"""
+import os, sys, threading
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from helpers import assert_parity, assert_rmcl_step, po, synth_csr
+from sparse_matrix_with_flops_amd import hipspgemm as hs
+from test_gpu_sharded_abi import _graph, to_hs_plain
+W = {world}
+A = synth_csr(30000, 23, 2)
+want = po.omp_spmm(A, A)
+Mt = _graph(12000, 31)
+ident = hs.unique_id()
+res, errs = [None] * W, []
+def rank(r):
+    try:
+        g = hs.Group.of_rank(W, r, 0, ident)                 # blocks until every rank has joined, like ncclCommInitRank
+        assert (g.nranks, g.nlocal, g.transport) == (W, 1, hs.XCHG_RCCL)
+        job = hs.ShardedSpMM(g, to_hs_plain(A))
+        for _ in range(2):
+            nnz, P = job.step(gather=True)
+        full = job.result(0)
+        nnz_blk, _ = job.step(gather=False)
+        blk = job.result(0)
+        info = job.info()
+        job.close()
+        nxt = hs.gpuRmclIter_sharded(g, 2, to_hs_plain(Mt), to_hs_plain(Mt))
+        g.close()
+        res[r] = (nnz, P, full, nnz_blk, blk, info, nxt)
+    except BaseException as e:                               # noqa: BLE001
+        errs.append((r, repr(e)))
+ts = [threading.Thread(target=rank, args=(r,)) for r in range(W)]
+[t.start() for t in ts]
+[t.join() for t in ts]
+assert not errs, errs
+flops = po.row_flops(A, A)
+prefix = np.concatenate([[0], np.cumsum(flops)]).astype(np.int64)
+ends = po.equal_partition64(prefix, W)
+one = None
+for r in range(W):
+    nnz, P, full, nnz_blk, blk, info, nxt = res[r]
+    assert nnz == want.nnz and P == int(prefix[-1]) and np.array_equal(info["ends"], ends)
+    assert_parity(full, want, what="rank %d of %d: gathered C" % (r, W))      # EVERY rank holds the whole product
+    r0, r1 = ends[r], ends[r + 1]
+    assert blk.rows == r1 - r0
+    sub = po.CSRHost(want.rowPtr[r0:r1 + 1] - want.rowPtr[r0], want.colInd[want.rowPtr[r0]:want.rowPtr[r1]],
+                     want.values[want.rowPtr[r0]:want.rowPtr[r1]], r1 - r0, A.cols)
+    assert_parity(blk, sub, what="rank %d: own block" % r)
+    got = po.CSRHost(nxt.rowPtr, nxt.colInd, nxt.values, Mt.rows, Mt.cols)
+    if one is None:
+        one = got
+        first = hs.gpuRmclIter_sharded(hs.Group(1, devices=[0], transport=hs.XCHG_PEER), 1, to_hs_plain(Mt), to_hs_plain(Mt))
+        assert_rmcl_step(got, Mt, po.CSRHost(first.rowPtr, first.colInd, first.values, Mt.rows, Mt.cols), what="2 iterations over %d ranks" % W)
+    else:                                                    # every rank returns the SAME matrix (it was gathered)
+        assert np.array_equal(got.rowPtr, one.rowPtr) and np.array_equal(got.colInd, one.colInd) and np.array_equal(got.values, one.values)
+maps = open("/proc/self/maps").read()                      # the exchange really went through the stand-in
+assert "libloopback_rccl.so" in maps and "librccl.so" not in maps
+print("loopback ok", W)
+"""
+
+
+def to_hs_plain(M):
+    return hs.CSR.from_arrays(M.rowPtr, M.colInd, M.values, M.rows, M.cols)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_groups_exchange_over_a_loopback_rccl(world):
+    """The multi-PROCESS form of the group (spgemm_hip_group_create_rank: one shard per rank, RCCL the only transport) with
+    peers != self -- what bench.py --gpus N and an 8-GPU node run -- cannot execute on a one-GPU box with the real RCCL
+    (two ranks on one device are refused).  tests/cpp/loopback_rccl.cc stands in for the nine RCCL entry points the library
+    loads (SPGEMM_RCCL_LIB): ranks are THREADS sharing the GPU, sends and receives are matched per pair in posting order
+    as NCCL does, a size mismatch is an error and an unmatched receive blocks.  Checked: the communicator set-up from a
+    distributed id, ncclAllGather of the segment sizes, the grouped ncclSend/ncclRecv of the three arrays per peer with
+    their counts and offsets, the R-MCL loop's gather of pruned blocks -- every rank ends with the oracle's product.
+    Own process: the library loads its RCCL once."""
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "libloopback_rccl.so"])
+    env = dict(os.environ, SPGEMM_RCCL_LIB=os.path.join(ROOT, "tests", "cpp", "libloopback_rccl.so"))
+    out = subprocess.run([sys.executable, "-c", _LOOPBACK_SCRIPT.format(root=ROOT, world=world)], capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert out.returncode == 0 and f"loopback ok {world}" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
