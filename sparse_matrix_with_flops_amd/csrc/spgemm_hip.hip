@@ -1352,7 +1352,7 @@ static int rmcl_pack_rows(spgemm_handle* h, int m, const int* starts, const int*
 static int rmcl_expand_prune_core(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, int nnzA,
                                   const int* dIB, const int* dIBlen, const int2* dIBse, const int* dJB, const float* dB,
                                   int nnzB, int m, int k, int n, bool pack, int** dIN, int** dLenN, int2** dSEN,
-                                  int** dJN, float** dCN, int* nnzN) {
+                                  int** dJN, float** dCN, int* nnzN, bool* errPending = nullptr) {
   *dIN = nullptr; *dLenN = nullptr; *dSEN = nullptr; *dJN = nullptr; *dCN = nullptr; *nnzN = 0;
   HIPCHK(hipSetDevice(h->device));
   auto two_steps = [&]() {                           // no rows, no products, or a product too large for the scratch C
@@ -1392,6 +1392,10 @@ static int rmcl_expand_prune_core(spgemm_handle* h, const int* dIA, const int* d
     return hipfail("classification copy");
   if (hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)m + 1), s) != hipSuccess) return hipfail("memset");
   if (hipEventSynchronize(h->evMid) != hipSuccess) return hipfail("classification");
+  if (errPending && *errPending) {                   // the previous iteration of the loop returned without waiting for its
+    *errPending = false;                             // numeric kernels: their flags reached the host before this event
+    if (h->hsmall->err) return cleanup(fail(SPGEMM_ERR_INTERNAL, "device invariant broken in the previous iteration (flags=%d)", h->hsmall->err));
+  }
   const HostMirror mid = *h->hmid;
   const unsigned long long P = mid.totalP;
   // products beyond which the scratch C (8 bytes per product) is not made and the step runs as SpGEMM + prune.
@@ -1432,9 +1436,26 @@ static int rmcl_expand_prune_core(spgemm_handle* h, const int* dIA, const int* d
   if ((rc = launch_numeric(h, dIA, dA, dJB, dB, n, h->cur_rowIds, mid.binPtr, dIC, dJC, dC, cnt, nosym ? 2 : 1))) return cleanup(rc);
   hipEventRecord(h->ev[5], s);
   if (pack && (rc = launch_scan(h, cnt, m, &h->dsmall->kept64))) return cleanup(rc);
-  if (hipMemcpyAsync(h->hsmall, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
-      hipStreamSynchronize(s) != hipSuccess)
+  if (hipMemcpyAsync(h->hsmall, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess)
     return hipfail("numeric phase");
+  if (!pack && errPending && h->ktiming == 0) {
+    // Loop form: nothing of this iteration is needed on the host before the next one starts -- its classification is
+    // queued behind the numeric kernels, and the error flags are looked at after that classification's event (above).
+    // The host runs ahead and the GPU does not idle between iterations.  (With per-kernel timing on, the events have to
+    // be read now: the call waits as before.)
+    int2* se = nullptr;
+    if (hipSuccess != pool().alloc((void**)&se, sizeof(int2) * (size_t)m)) return hipfail("device allocation failed");
+    hipLaunchKernelGGL(k_zip_extents, dim3(cdiv(m, 256)), dim3(256), 0, s, m, dIC, cnt, se);
+    if (hipGetLastError() != hipSuccess) { pool().release(se); return hipfail("extent launch"); }
+    spgemm_stats& st0 = h->stats;
+    st0.total_flops = (long long)mid.totalP;
+    st0.nnzC = -1;
+    for (int b = 0; b < NBINS; ++b) st0.bin_rows[b] = mid.binPtr[b + 1] - mid.binPtr[b];
+    *errPending = true;
+    *dIN = dIC; *dLenN = cnt; *dSEN = se; *dJN = dJC; *dCN = dC; *nnzN = (int)P;
+    return SPGEMM_OK;
+  }
+  if (hipStreamSynchronize(s) != hipSuccess) return hipfail("numeric phase");
   h->mirror = *h->hsmall;
   const HostMirror& hm = h->mirror;
   if (hm.err) return cleanup(fail(SPGEMM_ERR_INTERNAL, "device invariant broken (flags=%d)", hm.err));
@@ -1511,34 +1532,42 @@ extern "C" int hip_gpuRmclIter_device(spgemm_handle* h, int maxIter, int rows, i
   int *cI = nullptr, *cLen = nullptr, *cJ = nullptr;                    // the current Mt when the loop owns it
   int2* cSE = nullptr;
   float* cV = nullptr;
+  // An iteration that leaves Mt unpacked returns WITHOUT waiting for its numeric kernels (they read the previous Mt):
+  // that Mt goes to `old` and is released one iteration later, after a call that has waited for an event recorded behind
+  // those kernels -- the pool hands blocks to other handles and streams, so stream order alone does not protect them.
+  std::vector<void*> old;
+  auto flush_old = [&]() { for (void* q : old) pool().release(q); old.clear(); };
   auto drop = [&]() {
-    for (void* q : {(void*)cI, (void*)cLen, (void*)cSE, (void*)cJ, (void*)cV}) pool().release(q);
+    for (void* q : {(void*)cI, (void*)cLen, (void*)cSE, (void*)cJ, (void*)cV}) if (q) old.push_back(q);
     cI = cLen = cJ = nullptr; cSE = nullptr; cV = nullptr;
   };
+  bool errPending = false;
+  auto bail = [&](int rc) { (void)hipStreamSynchronize(h->stream); drop(); flush_old(); return rc; };
   for (int it = 0; it < maxIter; ++it) {
     int *nI = nullptr, *nLen = nullptr, *nJ = nullptr, nn = 0;
     int2* nSE = nullptr;
     float* nV = nullptr;
     const bool pack = keep_packed || it == maxIter - 1;
     const int rc = rmcl_expand_prune_core(h, dgI, dgJ, dgA, gnnz, bI, bLen, bSE, bJ, bV, bn, rows, cols, cols, pack, &nI,
-                                          &nLen, &nSE, &nJ, &nV, &nn);
-    if (rc) { drop(); return rc; }
-    drop();
+                                          &nLen, &nSE, &nJ, &nV, &nn, &errPending);
+    if (rc) return bail(rc);
+    flush_old();                                     // the call above waited behind the kernels that read these
+    drop();                                          // the Mt it read itself: released after the next call
     cI = nI; cLen = nLen; cSE = nSE; cJ = nJ; cV = nV;
     bI = cI; bLen = cLen; bSE = cSE; bJ = cJ; bV = cV; bn = nn;
   }
+  flush_old();                                       // the last iteration packs and waits for everything
   if (maxIter == 0) {                                // a copy of Mt
     const size_t bi = sizeof(int) * ((size_t)rows + 1), bj = sizeof(int) * (size_t)std::max(tnnz, 1);
     if (hipSuccess != pool().alloc((void**)&cI, bi) || hipSuccess != pool().alloc((void**)&cJ, bj) ||
-        hipSuccess != pool().alloc((void**)&cV, bj)) { drop(); return fail(SPGEMM_ERR_NOMEM, "device allocation failed"); }
+        hipSuccess != pool().alloc((void**)&cV, bj)) { return bail(fail(SPGEMM_ERR_NOMEM, "device allocation failed")); }
     if (hipMemcpyAsync(cI, dtI, bi, hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
         (tnnz > 0 && (hipMemcpyAsync(cJ, dtJ, sizeof(int) * (size_t)tnnz, hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
                       hipMemcpyAsync(cV, dtA, sizeof(float) * (size_t)tnnz, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)) ||
-        hipStreamSynchronize(h->stream) != hipSuccess) { drop(); return fail(SPGEMM_ERR_HIP, "copy of Mt"); }
+        hipStreamSynchronize(h->stream) != hipSuccess) { return bail(fail(SPGEMM_ERR_HIP, "copy of Mt")); }
     bn = tnnz;
   } else if (bLen) {                                 // the last iteration gave up on the fused step?  it returns packed: not reached
-    drop();
-    return fail(SPGEMM_ERR_INTERNAL, "the last iteration returned an unpacked matrix");
+    return bail(fail(SPGEMM_ERR_INTERNAL, "the last iteration returned an unpacked matrix"));
   }
   *oI = cI; *oJ = cJ; *oA = cV; *onnz = bn;
   return SPGEMM_OK;
