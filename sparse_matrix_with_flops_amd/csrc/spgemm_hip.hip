@@ -62,6 +62,8 @@ namespace {
 // spgemm_hip_free / release() is idle; callers that queue their own work on such a block must finish it before freeing
 // (the same rule cudaFree imposes implicitly by synchronising).  SPGEMM_POOL_CHECK=1 makes release() synchronise the
 // device first (debugging aid for foreign streams).
+// One entry point queues work and returns before it has completed: an iteration of hip_gpuRmclIter_device that leaves Mt
+// unpacked.  The loop keeps the blocks those kernels read out of the pool until a later wait has covered them.
 struct DevPool {
   struct Blk { size_t size; int dev; };
   std::mutex mu;
