@@ -1743,6 +1743,19 @@ __device__ __forceinline__ unsigned bh_class(int col, unsigned npass) {
   return ((((unsigned)col * 0x85ebca6bu) >> 16) * npass) >> 16;     // second hash, independent of the slot hash
 }
 
+#ifdef SMF_STAMPS
+// diagnostic build: cycles of wave 0 of every block, summed per phase of k_num_bighash (read with spgemm_hip_debug_stamps)
+__device__ unsigned long long g_stamps[16];
+#define STAMP_DECL unsigned long long st_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long t_ = __builtin_readcyclecounter(); const unsigned long long t0_ = t_;
+#define STAMP(i) { const unsigned long long n_ = __builtin_readcyclecounter(); st_[i] += n_ - t_; t_ = n_; }
+#define STAMP_IN(var) const unsigned long long var = __builtin_readcyclecounter();
+#define STAMP_OUT(i, var) { st_[i] += __builtin_readcyclecounter() - var; }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_IN(var)
+#define STAMP_OUT(i, var)
+#endif
 __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restrict__ binPtr, int bin,
                                                              const int* __restrict__ rowIds,
                                                              const int* __restrict__ IA, const int2* __restrict__ SBL,
@@ -1759,6 +1772,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
   const int first = binPtr[bin], count = binPtr[bin + 1] - first;
   int2* const park = spill ? spill + (size_t)blockIdx.x * (size_t)spillCap : nullptr;
   if (tid < WAVE) sh.st.dummy[tid] = DUMMY_SLOT;
+  STAMP_DECL
   int q = next_row(qctr, &sh.red[0]);                 // one row ahead, as in k_sym_big
   RowMeta cur = load_meta_num(rowIds + first, q, count, IA, IC, rowFlops);
   while (q < count) {
@@ -1782,14 +1796,17 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
     const int shift = 0;
     const int per = size / BIG_NW;
     bool useSpill = canSpill;
+    STAMP(0)
     for (unsigned pass = 0; pass < npass;) {
       clear_slots(sh.tab, size, tid, BIG_THREADS);
       if (pass == 0 && tid < BH_MAXCLS) sh.spillCnt[tid] = 0;
       if (pass == 0 && tid == 0) { sh.emitted = 0; sh.ovf = 0; }
       __syncthreads();
+      STAMP(1)
       if (pass == 0 || !useSpill) {
         for_each_product<BIG_NW, BH_U, true>(sh.st, as, ae, SBL, VA, JB, VB,
                                               [&](const bool (&act)[BH_U], const int (&col)[BH_U], const float (&val)[BH_U], int) {
+          STAMP_IN(ti_)
           bool mine[BH_U];
           unsigned cls[BH_U];
 #pragma unroll
@@ -1798,6 +1815,8 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
             mine[u] = act[u] && cls[u] == pass;
           }
           hash_accum_multi<false>(sh.tab, size, shift, mine, col, val, &sh.st.dummy[lane_id()], err);
+          STAMP_OUT(3, ti_)
+          STAMP_IN(tp_)
           if (useSpill) {                              // block-uniform; here pass == 0
             for (unsigned c = 1; c < npass; ++c) {
               unsigned long long mk[BH_U];
@@ -1821,7 +1840,9 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
               }
             }
           }
+          STAMP_OUT(4, tp_)
         });
+        STAMP(2)
         if (pass == 0 && useSpill && sh.ovf) {        // block-uniform (read after the walk's closing barrier)
           __syncthreads();                             // everyone has seen the flag before it is reset
           useSpill = false;
@@ -1852,18 +1873,28 @@ __global__ __launch_bounds__(BIG_THREADS) void k_num_bighash(const int* __restri
           hash_accum_multi<false>(sh.tab, size, shift, mine, col, val, &sh.st.dummy[lane_id()], err);
         }
         __syncthreads();
+        STAMP(5)
       }
       // compaction: wave w emits the slots [w*per, w*per+per); its share of the row's output range comes from one
       // LDS atomic (the counter runs on across the passes of a row)
       emit_claimed<BH_SLOTS / BIG_NW / WAVE>(sh.tab, w * per, per, &sh.emitted, outBase, outEnd, JC, C);
       __syncthreads();
+      STAMP(6)
       ++pass;
     }
     if (tid == 0 && sh.emitted != want) atomicOr(err, ERRF_COUNT_MISMATCH);
     __syncthreads();
     cur = nxt;
     q = qn;
+    STAMP(7)
   }
+#ifdef SMF_STAMPS
+  if (tid == 0) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], st_[i]);
+    atomicAdd(&g_stamps[8], __builtin_readcyclecounter() - t0_);
+    atomicAdd(&g_stamps[9], 1ull);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

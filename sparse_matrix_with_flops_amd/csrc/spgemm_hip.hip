@@ -1717,3 +1717,13 @@ extern "C" int spgemm_hip_selftest(spgemm_handle* h) {
 // multi-GPU: groups of shards, sharded SpGEMM, sharded R-MCL
 // ------------------------------------------------------------------------------------------------
 #include "sharded.hpp"
+
+#ifdef SMF_STAMPS
+// diagnostic build only: the phase cycles k_num_bighash has accumulated since the last call (and reset)
+extern "C" int spgemm_hip_debug_stamps(unsigned long long* out16) {
+  unsigned long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(z)) != hipSuccess) return fail(SPGEMM_ERR_HIP, "stamps");
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return fail(SPGEMM_ERR_HIP, "stamps reset");
+  return SPGEMM_OK;
+}
+#endif
