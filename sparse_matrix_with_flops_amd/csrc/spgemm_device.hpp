@@ -1515,10 +1515,16 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
 //   numeric B: any n: 128 KB LDS hash table; rows with more distinct columns than one table holds take
 //              several passes, each pass owning the columns of one hash class
 // ------------------------------------------------------------------------------------------------
-constexpr int BIG_NW = 16;
+#ifndef SMF_BIG_NW
+#define SMF_BIG_NW 16
+#endif
+constexpr int BIG_NW = SMF_BIG_NW;   // (SMF_BIG_NW: diagnostic builds with fewer waves per big-row block)
 constexpr int BIG_THREADS = BIG_NW * WAVE;
 constexpr int BIG_U = 4;                        // rounds in flight per wave: bitmap / rank kernels
-constexpr int BH_U = 2;                         // ... and the big-row hash kernel (probe chains: 2 measured better than 4)
+#ifndef SMF_BH_U
+#define SMF_BH_U 2
+#endif
+constexpr int BH_U = SMF_BH_U;                         // ... and the big-row hash kernel (probe chains: 2 measured better than 4)
 constexpr int SYM_WC = 1 << 20;                // columns per symbolic window (128 KB bitmap)
 constexpr int SYM_WORDS = SYM_WC / 32;
 constexpr int BIG_WC = 262144;                 // columns covered by the rank kernel (32 KB bitmap)
