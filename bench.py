@@ -92,6 +92,8 @@ KERNEL_BINS = {
     "k_num_g16<32,1>": ((1, 2, 3), "num"), "k_num_g16": ((4,), "num"), "k_num_hash<1,1024>": ((5,), "num"),
     "k_num_hash<4,4096>": ((6,), "num"), "k_num_hash<8,8192>": ((7,), "num"), "k_num_big": ((8,), "num"),
     "k_num_bighash": ((8,), "num"),
+    # round 4, the one-pass kernel: classification aside, everything BYTES_ALG credits for its rows happens in this launch
+    "k_chain": (((0, 1, 2, 3, 4, 5, 6, 7) if os.environ.get("SPGEMM_CHAIN_CFG") == "2" else (0, 1, 2, 3, 4, 5, 6)), "num"),
 }
 
 

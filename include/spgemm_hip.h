@@ -58,7 +58,8 @@ enum {
   SPGEMM_K_SYM_SMALL4, SPGEMM_K_SYM_G16, SPGEMM_K_SYM_HASH1, SPGEMM_K_SYM_HASH4, SPGEMM_K_SYM_HASH8, SPGEMM_K_SYM_BIG,
   SPGEMM_K_SCAN,
   SPGEMM_K_NUM_SMALL4, SPGEMM_K_NUM_G16, SPGEMM_K_NUM_HASH1, SPGEMM_K_NUM_HASH4, SPGEMM_K_NUM_HASH8, SPGEMM_K_NUM_BIG,
-  SPGEMM_K_NUM_BIGHASH
+  SPGEMM_K_NUM_BIGHASH,
+  SPGEMM_K_CUT, SPGEMM_K_CHAIN           /* round 4: the one-pass path (cut of the rows into batches; accumulate + chained prefix) */
 };
 const char* spgemm_hip_kernel_name(int id);
 

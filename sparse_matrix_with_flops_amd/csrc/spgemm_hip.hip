@@ -3,6 +3,7 @@
 // spgemm_device.hpp.  gfx950 only.  There is NO CPU fallback in this library: without a HIP device
 // every entry point fails with SPGEMM_ERR_NODEVICE / SPGEMM_ERR_HIP.
 #include "spgemm_device.hpp"
+#include "chain_device.hpp"
 #include "../../include/spgemm_hip.h"
 
 #include <algorithm>
@@ -156,6 +157,10 @@ struct HostMirror {                 // one small device block + its pinned host 
   unsigned long long totalP;
   unsigned long long nnzC64;
   unsigned long long kept64;        // entries that survive the fused R-MCL prune
+  unsigned long long cutTotal;      // one-pass path (chain_device.hpp): total of the cut scan (unused), batches, ticket counter
+  int nBatches;
+  alignas(128) int chainTicket;
+  alignas(128) int chainPad_;
 };
 
 struct spgemm_handle {
@@ -173,6 +178,10 @@ struct spgemm_handle {
   unsigned long long* tileSum = nullptr;
   unsigned long long* blockP = nullptr;     // per-block sums of row flops (reduced by k_bin_scan)
   int2* sbl = nullptr;                       // per A entry {B-row start, B-row length} (k_entry_lens), cap_nnz entries
+  int* batchStart = nullptr;                 // one-pass path: first row of every batch (3*cap_m + 64 entries)
+  unsigned long long* chainWords = nullptr;  // ... and the batches' words of the chained prefix
+  bool useChain = true;                      // SPGEMM_CHAIN=0: the two-pass pipeline for every row
+  int chainCfg = 0;                          // SPGEMM_CHAIN_CFG: kernel geometry (experiments)
   long long cap_nnz = -1;
   HostMirror* dsmall = nullptr;
   HostMirror* hsmall = nullptr;
@@ -213,7 +222,8 @@ static std::map<int, int> g_handles_on;          // device -> live handles (the 
 
 static int ws_free(spgemm_handle* h) {
   hipFree(h->rowFlops); hipFree(h->binId); hipFree(h->blockHist); hipFree(h->blockOff);
-  hipFree(h->rowIds); hipFree(h->tileSum); hipFree(h->blockP);
+  hipFree(h->rowIds); hipFree(h->tileSum); hipFree(h->blockP); hipFree(h->batchStart); hipFree(h->chainWords);
+  h->batchStart = nullptr; h->chainWords = nullptr;
   h->rowFlops = nullptr; h->binId = nullptr; h->blockHist = nullptr; h->blockOff = nullptr;
   h->rowIds = nullptr; h->tileSum = nullptr; h->blockP = nullptr; h->cap_m = -1;
   return SPGEMM_OK;
@@ -242,6 +252,8 @@ static int ws_ensure(spgemm_handle* h, int m) {
   HIPCHK(hipMalloc((void**)&h->rowIds, sizeof(int) * cap));
   HIPCHK(hipMalloc((void**)&h->tileSum, sizeof(unsigned long long) * ntile));
   HIPCHK(hipMalloc((void**)&h->blockP, sizeof(unsigned long long) * nblk));
+  HIPCHK(hipMalloc((void**)&h->batchStart, sizeof(int) * (3 * cap + 64)));
+  HIPCHK(hipMalloc((void**)&h->chainWords, sizeof(unsigned long long) * (3 * cap + 64)));
   h->cap_m = (int)std::min<size_t>(cap, 0x7fffffff);
   return SPGEMM_OK;
 }
@@ -279,6 +291,8 @@ extern "C" int spgemm_hip_create(spgemm_handle** out, int device) {
   { const char* e = getenv("SPGEMM_H1SYM"); if (e) { const int c = atoi(e); if (c >= 1 && c <= 32) h->h1sym = c; } }
   { const char* e = getenv("SPGEMM_BHMARGIN"); if (e) { const int c = atoi(e); if (c >= 10 && c <= 400) h->bhMargin = c; } }
   { const char* e = getenv("SPGEMM_BHCAP"); if (e) { const int c = atoi(e); if (c >= 1024 && c <= BH_CAP_MAX) h->bhCap = c; } }
+  { const char* e = getenv("SPGEMM_CHAIN"); if (e) h->useChain = e[0] != '0'; }
+  { const char* e = getenv("SPGEMM_CHAIN_CFG"); if (e) h->chainCfg = atoi(e); }
   { const char* e = getenv("SPGEMM_U"); if (e) { const int u = atoi(e); if (u == 2 || u == 4 || u == 8) h->U = u; } }
   for (auto& st : h->side) {
     if (h->serial) st = h->stream;
@@ -430,7 +444,8 @@ static inline int grid8(long long want, int hi) { return (clampi(want, 8, hi) + 
 static const char* kKernelNames[SPGEMM_NKERNELS] = {
     "k_row_flops", "k_bin_scan", "k_scatter_rows", "k_sym_g16<32,1>", "k_sym_g16", "k_sym_hash<1,1024>",
     "k_sym_hash<4,4096>", "k_sym_hash<8,8192>", "k_sym_big", "k_scan(3 launches)", "k_num_g16<32,1>", "k_num_g16",
-    "k_num_hash<1,1024>", "k_num_hash<4,4096>", "k_num_hash<8,8192>", "k_num_big", "k_num_bighash", "", "", ""};
+    "k_num_hash<1,1024>", "k_num_hash<4,4096>", "k_num_hash<8,8192>", "k_num_big", "k_num_bighash", "k_cut(3 launches)",
+    "k_chain", ""};
 extern "C" const char* spgemm_hip_kernel_name(int id) { return (id >= 0 && id < SPGEMM_NKERNELS) ? kKernelNames[id] : ""; }
 
 // every launch is bracketed by two events on its stream (per-kernel durations for bench.py's roofline)
@@ -513,7 +528,7 @@ static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, con
 // symbolic pass over bins 2..8 (bins 0/1 were preset by K1).  Bin sizes are not known on the host
 // here (no sync): grids are capped by the CU count and every block strides / dequeues over its bin.
 static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJB,
-                           int m, int n, const int* rowIds, int* dIC) {
+                           int m, int n, const int* rowIds, int* dIC, int minBin = 0) {
   const int2* sbl = h->sbl;
   if (m <= 0) return SPGEMM_OK;
   clear_stale_hip_error();
@@ -525,23 +540,23 @@ static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJB,
   { hipStream_t st = h->side[3]; KTimer t(h, SPGEMM_K_SYM_BIG, st);
     hipLaunchKernelGGL(k_sym_big, dim3(clampi(m, 1, cu)), dim3(BIG_THREADS), sizeof(BigSymShared), st, bp, 8,
                        rowIds, dIA, sbl, dJB, n, dIC, h->bigBitmaps, h->bm_cap, qc + 0 * 32); }
-  { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_SYM_HASH8, st);
+  if (minBin <= 7) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_SYM_HASH8, st);
     LAUNCH_U(k_sym_hash, 8, 8192, dim3(clampi(m, 1, cu * 3)), dim3(512), st, bp, 7, rowIds, dIA,
              sbl, dJB, h->rowFlops, dIC, err, qc + 1 * 32); }
-  { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_SYM_HASH4, st);
+  if (minBin <= 6) { hipStream_t st = h->side[2]; KTimer t(h, SPGEMM_K_SYM_HASH4, st);
     // (one launch for both layout slots of bin 6: split like the numeric side it measured 15 % slower)
     LAUNCH_U(k_sym_hash, 4, 4096, dim3(clampi(m, 1, cu * 8)), dim3(256), st, bp, 6, rowIds, dIA,
              sbl, dJB, h->rowFlops, dIC, err, qc + 2 * 32); }
-  { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_SYM_HASH1, st);
+  if (minBin <= 5) { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_SYM_HASH1, st);
     const int* sb = h->dsmall->slotBase;         // bin 5 = two layout slots: table 512 up to 256 products, 1024 above
     LAUNCH_U(k_sym_hash, 1, 512, dim3(grid8(m, cu * h->h1sym)), dim3(64), st, sb, SLOT_H1A, rowIds, dIA,
              sbl, dJB, h->rowFlops, dIC, err, qc + 3 * 32);
     LAUNCH_U(k_sym_hash, 1, 1024, dim3(grid8(m, cu * h->h1sym)), dim3(64), st, sb, SLOT_H1B, rowIds, dIA,
              sbl, dJB, h->rowFlops, dIC, err, qc + 3 * 32); }
-  { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_SYM_G16, st);
+  if (minBin <= 4) { hipStream_t st = h->side[0]; KTimer t(h, SPGEMM_K_SYM_G16, st);
     hipLaunchKernelGGL((k_sym_g16<128, 4>), dim3(grid8(cdiv(m, 16), cu * 16)), dim3(256), 0, st, bp, 4, 5,
                        rowIds, dIA, sbl, dJB, h->rowFlops, dIC, err); }
-  { KTimer t(h, SPGEMM_K_SYM_SMALL4);           // 2..16 products: the same 16-lane flattened kernel, one round per row
+  if (minBin <= 3) { KTimer t(h, SPGEMM_K_SYM_SMALL4);           // 2..16 products: the same 16-lane flattened kernel, one round per row
     hipLaunchKernelGGL((k_sym_g16<32, 1>), dim3(grid8(cdiv(m, 16), cu * 16)), dim3(256), 0, h->stream, bp, 2, 4,
                        rowIds, dIA, sbl, dJB, h->rowFlops, dIC, err); }
   join_streams(h);
@@ -563,7 +578,7 @@ static int launch_scan(spgemm_handle* h, int* cnt, int m, unsigned long long* dT
 
 static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
                           const int* dJB, const float* dB, int n, const int* rowIds, const int* hostBinPtr,
-                          const int* dIC, int* dJC, float* dC, int* pcnt = nullptr, int pmode = 1) {
+                          const int* dIC, int* dJC, float* dC, int* pcnt = nullptr, int pmode = 1, int minBin = 0) {
   // pcnt != nullptr: fused R-MCL prune -- every row leaves only its kept, normalised entries at the front of its range
   // of dJC/dC and their count in pcnt[row] (rows of bin 8 are written in full and fixed up in place right behind).
   // pmode 2: no symbolic pass ran below bin 8: dIC holds the prefix sums of the rows' product counts there, exact counts
@@ -574,7 +589,7 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
   int* err = &h->dsmall->err;
   int* qc = h->dsmall->qctr;
   const int cu = h->numCU;
-  auto rows = [&](int lo, int hi) { return hostBinPtr[hi] - hostBinPtr[lo]; };
+  auto rows = [&](int lo, int hi) { return lo < minBin ? 0 : hostBinPtr[hi] - hostBinPtr[lo]; };   // (lo = the lowest bin of the launch)
   fork_streams(h);
   if (rows(8, 9) > 0) {
     hipStream_t st = h->side[3];
@@ -623,7 +638,7 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
                                       bp, 4, 5, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, h->rowFlops, pcnt);
     else hipLaunchKernelGGL((k_num_g16<128, 4>), dim3(grid8(cdiv(rows(4, 5), 16), cu * 16)), dim3(256), 0, st,
                             bp, 4, 5, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, h->rowFlops, (int*)nullptr); }
-  if (rows(1, 4) > 0) { KTimer t(h, SPGEMM_K_NUM_SMALL4);   // 1..16 products: 16-lane flattened kernel, one round per row
+  if (minBin <= 1 && rows(1, 4) > 0) { KTimer t(h, SPGEMM_K_NUM_SMALL4);   // 1..16 products: 16-lane flattened kernel, one round per row
     if (pcnt && pmode == 2) hipLaunchKernelGGL((k_num_g16<32, 1, 2>), dim3(grid8(cdiv(rows(1, 4), 16), cu * 16)), dim3(256), 0, h->stream,
                                                bp, 1, 4, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, h->rowFlops, pcnt);
     else if (pcnt) hipLaunchKernelGGL((k_num_g16<32, 1, 1>), dim3(grid8(cdiv(rows(1, 4), 16), cu * 16)), dim3(256), 0, h->stream,
@@ -631,6 +646,66 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
     else hipLaunchKernelGGL((k_num_g16<32, 1>), dim3(grid8(cdiv(rows(1, 4), 16), cu * 16)), dim3(256), 0, h->stream,
                             bp, 1, 4, rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, h->rowFlops, (int*)nullptr); }
   join_streams(h);
+  HIPCHK(hipGetLastError());
+  return SPGEMM_OK;
+}
+
+// ---- the one-pass path (chain_device.hpp)
+// geometry: waves per block, pool slots, rows per batch, blocks per CU; rows up to smallMax products share batches, rows
+// up to rmax are a batch of their own, rows beyond (bins >= minBin of the old layout) keep their two kernels
+struct ChainCfg { int nw, pool, rb, bpc, smallMax, rmax, minBin; };
+static const ChainCfg kChainCfgs[] = {
+    {8, 4352, 256, 3, 512, 2048, 7},
+    {12, 6912, 256, 2, 768, 2048, 7},
+    {16, 8192, 256, 1, 1024, 4096, 8},
+    {8, 7680, 256, 2, 1024, 2048, 7},
+    {8, 7680, 256, 2, 2048, 2048, 7},       // 4: no solo class: every row up to 2048 products shares windows of 3584 slots
+    {16, 8192, 256, 1, 2048, 2048, 7},      // 5: the same on one 16-wave block per CU
+    {12, 6912, 256, 2, 1536, 1536, 7},      // 6 (rows above 1536 products: not handled -> needs rmax on a bin edge; experiment only)
+};
+static const ChainCfg& chain_cfg(const spgemm_handle* h) {
+  const int n = (int)(sizeof(kChainCfgs) / sizeof(kChainCfgs[0]));
+  return kChainCfgs[h->chainCfg >= 0 && h->chainCfg < n ? h->chainCfg : 0];
+}
+
+static int launch_cut(spgemm_handle* h, int m) {
+  const ChainCfg& c = chain_cfg(h);
+  const int ntiles = std::max(1, cdiv(m, SCAN_TILE));
+  const CutParams p{c.smallMax, c.rmax, c.pool - 2 * c.smallMax, c.rb};
+  clear_stale_hip_error();
+  KTimer t(h, SPGEMM_K_CUT);
+  hipLaunchKernelGGL(k_cut_sums, dim3(ntiles), dim3(SCAN_THREADS), 0, h->stream, m, h->rowFlops, p, h->tileSum);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, h->stream, ntiles, h->tileSum, &h->dsmall->cutTotal);
+  hipLaunchKernelGGL(k_cut_apply, dim3(ntiles), dim3(SCAN_THREADS), 0, h->stream, m, h->rowFlops, p, h->tileSum,
+                     h->batchStart, h->chainWords, &h->dsmall->nBatches);
+  HIPCHK(hipGetLastError());
+  return SPGEMM_OK;
+}
+
+template <int NW, int POOL, int RB>
+static void launch_chain_t(spgemm_handle* h, int blocks, int m, const int* dIA, const float* dA, const int* dJB, const float* dB,
+                           int rmax, int* dIC, int* dJC, float* dC, long long capC) {
+  typedef ChainShared<NW, POOL, RB> Sh;
+  static bool attr = false;                              // (more than 64 KB of dynamic LDS needs the attribute once)
+  if (!attr) { (void)hipFuncSetAttribute((const void*)k_chain<NW, POOL, RB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Sh)); attr = true; }
+  hipLaunchKernelGGL((k_chain<NW, POOL, RB, 2>), dim3(blocks), dim3(WAVE * NW), sizeof(Sh), h->stream, m, dIA, h->sbl, dA, dJB, dB,
+                     h->rowFlops, rmax, h->batchStart, &h->dsmall->nBatches, h->chainWords, &h->dsmall->chainTicket, dIC, dJC, dC,
+                     capC, &h->dsmall->nnzC64, &h->dsmall->err);
+}
+
+static int launch_chain(spgemm_handle* h, int m, const int* dIA, const float* dA, const int* dJB, const float* dB,
+                        int* dIC, int* dJC, float* dC, long long capC) {
+  const ChainCfg& c = chain_cfg(h);
+  clear_stale_hip_error();
+  KTimer t(h, SPGEMM_K_CHAIN);
+  const int blocks = clampi((long long)h->numCU * c.bpc, 1, 1 << 20);
+  switch (h->chainCfg) {
+    case 1: launch_chain_t<12, 6912, 256>(h, blocks, m, dIA, dA, dJB, dB, c.rmax, dIC, dJC, dC, capC); break;
+    case 2: launch_chain_t<16, 8192, 256>(h, blocks, m, dIA, dA, dJB, dB, c.rmax, dIC, dJC, dC, capC); break;
+    case 3: case 4: launch_chain_t<8, 7680, 256>(h, blocks, m, dIA, dA, dJB, dB, c.rmax, dIC, dJC, dC, capC); break;
+    case 5: launch_chain_t<16, 8192, 256>(h, blocks, m, dIA, dA, dJB, dB, c.rmax, dIC, dJC, dC, capC); break;
+    default: launch_chain_t<8, 4352, 256>(h, blocks, m, dIA, dA, dJB, dB, c.rmax, dIC, dJC, dC, capC); break;
+  }
   HIPCHK(hipGetLastError());
   return SPGEMM_OK;
 }
@@ -757,13 +832,18 @@ static int spgemm_device(spgemm_handle* h, const int* dIA, const int* dJA, const
     h->cur_rowIds = h->rowIds;
     int rc = launch_classify(h, dIA, dJA, dIB, m, nnzA, dIC);
     if (rc) return cleanup(rc);
+    // One-pass path (chain_device.hpp, round 4): the rows up to ChainCfg::rmax products are accumulated and placed by ONE
+    // kernel (no symbolic pass, no scan); only the bins above keep their symbolic + numeric kernels.
+    const bool chainPath = h->useChain;
+    const int minBin = chainPath ? chain_cfg(h).minBin : 0;
+    if (chainPath && (rc = launch_cut(h, m))) return cleanup(rc);
     hipEventRecord(h->ev[1], s);
     if (hipMemcpyAsync(h->hmid, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipEventRecord(h->evMid, s) != hipSuccess)
       return cleanup(fail(SPGEMM_ERR_HIP, "classification copy failed: %s", hipGetErrorString(hipGetLastError())));
-    if ((rc = launch_symbolic(h, dIA, dJB, m, n, h->cur_rowIds, dIC))) return cleanup(rc);
+    if ((rc = launch_symbolic(h, dIA, dJB, m, n, h->cur_rowIds, dIC, minBin))) return cleanup(rc);
     hipEventRecord(h->ev[2], s);
-    if ((rc = launch_scan(h, dIC, m, &h->dsmall->nnzC64))) return cleanup(rc);
+    if (!chainPath && (rc = launch_scan(h, dIC, m, &h->dsmall->nnzC64))) return cleanup(rc);
     hipEventRecord(h->ev[3], s);
     if (hipEventSynchronize(h->evMid) != hipSuccess)
       return cleanup(fail(SPGEMM_ERR_HIP, "classification failed: %s", hipGetErrorString(hipGetLastError())));
@@ -774,14 +854,17 @@ static int spgemm_device(spgemm_handle* h, const int* dIA, const int* dJA, const
     // the two-phase path (exact allocation, one more host round trip -- cheap next to the halved footprint).
     const bool compressive = h->prev_m == m && h->prev_P == P && h->prev_nnzC >= 0 &&
                              (double)h->prev_nnzC < 0.75 * (double)P;
-    if (P <= (1ull << 30) && !compressive) {
-      const size_t capC = (size_t)std::max<unsigned long long>(P, 1ull);
+    // (one-pass path: a compressive product gets exactly the entries its previous, identical-looking call produced; the
+    // kernels never write past that and say so if it was not enough -- the call is then redone the two-phase way)
+    if (P <= (1ull << 30) && (!compressive || chainPath)) {
+      const size_t capC = compressive ? (size_t)std::max<long long>(h->prev_nnzC, 1ll) : (size_t)std::max<unsigned long long>(P, 1ull);
       if (hipSuccess != pool().alloc((void**)&dJC, sizeof(int) * capC) ||
           hipSuccess != pool().alloc((void**)&dC, sizeof(float) * capC))
         return cleanup(fail(SPGEMM_ERR_HIP, "device allocation of C (%llu entries) failed", P));
       hipEventRecord(h->ev[4], s);
       h->mirror = mid;                                 // bin sizes for the numeric launch grids
-      if (P > 0 && (rc = launch_numeric(h, dIA, dA, dJB, dB, n, h->cur_rowIds, mid.binPtr, dIC, dJC, dC))) return cleanup(rc);
+      if (chainPath && (rc = launch_chain(h, m, dIA, dA, dJB, dB, dIC, dJC, dC, (long long)capC))) return cleanup(rc);
+      if (P > 0 && (rc = launch_numeric(h, dIA, dA, dJB, dB, n, h->cur_rowIds, mid.binPtr, dIC, dJC, dC, nullptr, 1, minBin))) return cleanup(rc);
       hipEventRecord(h->ev[5], s);
       if (hipMemcpyAsync(h->hsmall, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
           hipStreamSynchronize(s) != hipSuccess)
@@ -789,6 +872,22 @@ static int spgemm_device(spgemm_handle* h, const int* dIA, const int* dJA, const
       h->mirror = *h->hsmall;
       h->sym_m = -1;
       const HostMirror& hm = h->mirror;
+      if (chainPath && (hm.err & ERRF_CHAIN_CAP)) {
+        // C sized from the previous call was too small for this product (same shape and product count, more distinct
+        // columns): nothing was written out of bounds; forget the guess and compute the product the two-phase way
+        pool().release(dJC); pool().release(dC);
+        dJC = nullptr; dC = nullptr;
+        h->prev_m = -1; h->prev_nnzC = -1;
+        rc = symbolic_phase(h, dIA, dJA, nnzA, dIB, dJB, m, k, n, nullptr, dIC, &nnzC);
+        if (rc) return cleanup(rc);
+        if (hipSuccess != pool().alloc((void**)&dJC, sizeof(int) * (size_t)std::max(nnzC, 1)) ||
+            hipSuccess != pool().alloc((void**)&dC, sizeof(float) * (size_t)std::max(nnzC, 1)))
+          return cleanup(fail(SPGEMM_ERR_HIP, "device allocation of C (%d entries) failed", nnzC));
+        rc = numeric_phase(h, dIA, dJA, dA, dIB, dJB, dB, m, n, dIC, dJC, dC);
+        if (rc) return cleanup(rc);
+        *dICp = dIC; *dJCp = dJC; *dCp = dC; *nnzCp = nnzC;
+        return SPGEMM_OK;
+      }
 #ifndef SMF_ABLATE
       if (hm.err) return cleanup(fail(SPGEMM_ERR_INTERNAL, "device invariant broken (flags=%d)", hm.err));
 #endif
@@ -809,6 +908,19 @@ static int spgemm_device(spgemm_handle* h, const int* dIA, const int* dJA, const
       return SPGEMM_OK;
     }
     // P too large for a speculative allocation: finish the symbolic phase the two-phase way (kernels already queued)
+    if (chainPath) {
+      // (the one-pass path queued only the symbolic kernels of its counted rows: run the whole two-pass pipeline instead)
+      rc = symbolic_phase(h, dIA, dJA, nnzA, dIB, dJB, m, k, n, nullptr, dIC, &nnzC);
+      if (rc) return cleanup(rc);
+      h->prev_m = m; h->prev_P = P; h->prev_nnzC = nnzC;
+      if (hipSuccess != pool().alloc((void**)&dJC, sizeof(int) * (size_t)std::max(nnzC, 1)) ||
+          hipSuccess != pool().alloc((void**)&dC, sizeof(float) * (size_t)std::max(nnzC, 1)))
+        return cleanup(fail(SPGEMM_ERR_HIP, "device allocation of C (%d entries) failed", nnzC));
+      rc = numeric_phase(h, dIA, dJA, dA, dIB, dJB, dB, m, n, dIC, dJC, dC);
+      if (rc) return cleanup(rc);
+      *dICp = dIC; *dJCp = dJC; *dCp = dC; *nnzCp = nnzC;
+      return SPGEMM_OK;
+    }
     if (hipMemcpyAsync(h->hsmall, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess)
       return cleanup(fail(SPGEMM_ERR_HIP, "symbolic phase failed: %s", hipGetErrorString(hipGetLastError())));
@@ -1724,6 +1836,12 @@ extern "C" int spgemm_hip_debug_stamps(unsigned long long* out16) {
   unsigned long long z[16] = {0};
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(z)) != hipSuccess) return fail(SPGEMM_ERR_HIP, "stamps");
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return fail(SPGEMM_ERR_HIP, "stamps reset");
+  return SPGEMM_OK;
+}
+extern "C" int spgemm_hip_debug_chain_stamps(unsigned long long* out16) {
+  unsigned long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_cstamps), sizeof(z)) != hipSuccess) return fail(SPGEMM_ERR_HIP, "stamps");
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_cstamps), z, sizeof(z)) != hipSuccess) return fail(SPGEMM_ERR_HIP, "stamps reset");
   return SPGEMM_OK;
 }
 #endif
