@@ -77,7 +77,7 @@ def emit(line):
 
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-ALL_KERNELS = 0xFFFFF
+ALL_KERNELS = 0x1FFFFF
 
 
 def bin_of(f):
@@ -93,7 +93,7 @@ KERNEL_BINS = {
     "k_num_hash<4,4096>": ((6,), "num"), "k_num_hash<8,8192>": ((7,), "num"), "k_num_big": ((8,), "num"),
     "k_num_bighash": ((8,), "num"),
     # round 4, the one-pass kernel: classification aside, everything BYTES_ALG credits for its rows happens in this launch
-    "k_chain": (((0, 1, 2, 3, 4, 5, 6, 7) if os.environ.get("SPGEMM_CHAIN_CFG") == "2" else (0, 1, 2, 3, 4, 5, 6)), "num"),
+    "k_chain": ((0, 1, 2, 3, 4, 5), "num"), "k_wbatch<num>": ((0, 1, 2, 3, 4, 5), "num"), "k_wbatch<sym>": ((0, 1, 2, 3, 4, 5), "sym"),
 }
 
 
@@ -106,23 +106,47 @@ def algorithmic_bytes(kind, rows, nnzA, P, nnzC):
     return 12 * rows + 12 * nnzA + 4 * P
 
 
+def device_code_hashes():
+    """sha256 of the kernel sources the shipped library was built from (its .buildinfo) -> {file: hash}"""
+    info = os.path.join(ROOT, "sparse_matrix_with_flops_amd", "libspgemm_hip.so.buildinfo")
+    out = {}
+    try:
+        lines = open(info).read().splitlines()
+        for ln in lines[lines.index("sources sha256:") + 1:]:
+            h_, name = ln.split()
+            if name.endswith("_device.hpp"):
+                out[name] = h_
+    except (OSError, ValueError):
+        pass
+    return out
+
+
 def traffic_for(workload, kernel, path=None):
     """PMC-derived HBM bytes per launch of `kernel` (profiles/collect.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes of
-    this same command), newest round first.  -> ({raw, fetch_x2}, source) or (None, None)."""
-    cands = [path] if path else [os.path.join(ROOT, "profiles", f"r{r:02d}_{workload}_traffic.json") for r in (3, 2, 1)]
+    this same command), newest round first.  -> ({raw, fetch_x2}, source) or (None, reason).
+    A traffic file is only believed when it records the hashes of the kernel sources it was collected on AND they equal the
+    hashes of the library in use (profiles/summarize.py writes them): bytes measured on other kernels are not reported."""
+    cands = [path] if path else [os.path.join(ROOT, "profiles", f"r{r:02d}_{workload}_traffic.json") for r in (4, 3, 2, 1)]
+    have = device_code_hashes()
+    stale = None
     # one timer id of the library covers BOTH launches of a split bin (tables of two sizes): their traffic adds up
     parts = {"k_num_hash<1,1024>": ("k_num_hash<1,512>", "k_num_hash<1,1024>"), "k_sym_hash<1,1024>": ("k_sym_hash<1,512>", "k_sym_hash<1,1024>"),
              "k_num_hash<4,4096>": ("k_num_hash<4,2048>", "k_num_hash<4,4096>")}.get(kernel, (kernel,))
     for tj in cands:
         if tj and os.path.exists(tj):
-            ks = json.load(open(tj)).get("kernels", {})
+            tjd = json.load(open(tj))
+            if not have or tjd.get("device_code_sha256") != have:
+                stale = stale or (f"{os.path.relpath(tj, ROOT)} was collected on other kernel sources than the library in use "
+                                  "(device_code_sha256 differs or is not recorded): not reported")
+                continue
+            ks = tjd.get("kernels", {})
             found = [ks[p_] for p_ in parts if p_ in ks]
             if found:
                 k = {f_: sum(x.get(f_, 0) for x in found) for f_ in ("hbm_bytes_raw", "hbm_bytes_fetch_x2")}
                 return ({"raw": k.get("hbm_bytes_raw"), "fetch_x2": k.get("hbm_bytes_fetch_x2")},
                         f"{os.path.relpath(tj, ROOT)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, collected "
-                        "separately (not in this run)")
-    return None, None
+                        "separately (not in this run) on the same kernel sources (device_code_sha256 checked)")
+    return None, stale
 
 
 def self_launch(args):
@@ -315,6 +339,7 @@ class GroupRunner:
 
 
 def bench_spgemm(ctx, args, wl):
+    """-> the result line as a dict (rank 0; None elsewhere).  Stops the process if the parity gate fails."""
     from sparse_matrix_with_flops_amd import synth
     hs, world, rank = ctx.hs, ctx.world, ctx.rank
     t0 = time.time()
@@ -338,6 +363,9 @@ def bench_spgemm(ctx, args, wl):
         if not ctx.all_ok(runner is not None):
             runner = None
             fallback = fallback or "another rank could not create its group"
+            if not args.allow_torch_exchange:
+                raise SystemExit(f"the library's RCCL group could not be made ({fallback}); an N>1 number has ONE provenance: "
+                                 "pass --allow-torch-exchange to fall back to the torch.distributed exchange of dist.py")
         if runner is not None:                                            # and one whole step through its exchange
             ok = True
             try:
@@ -347,6 +375,9 @@ def bench_spgemm(ctx, args, wl):
             if not ctx.all_ok(ok):
                 runner = None
                 fallback = fallback or "the first step failed on another rank"
+                if not args.allow_torch_exchange:
+                    raise SystemExit(f"the first step through the library's group failed ({fallback}); pass "
+                                     "--allow-torch-exchange to fall back to the torch.distributed exchange of dist.py")
     if runner is None:
         runner = TorchRunner(ctx, host, chunks)
 
@@ -405,7 +436,7 @@ def bench_spgemm(ctx, args, wl):
         "value": round(gflops, 3), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": wl["desc"], "name": args.workload, "m": m, "nnzA": nnzA, "intermediate_nnz_P": P,
+        "config": {"workload": wl["desc"], "name": wl["name"], "m": m, "nnzA": nnzA, "intermediate_nnz_P": P,
                    "nnzC": nnzC, "bytes_alg": bytes_alg,
                    "parallelism": ("single GPU" if world == 1 else f"A row-sharded by flops over {world} GPUs, B replicated, "
                                    "allgatherv of C's row segments over xGMI")},
@@ -442,7 +473,7 @@ def bench_spgemm(ctx, args, wl):
             nzc_ = sum(per_bin[q][3] for q in bins)
             ab = algorithmic_bytes(kind, rows_, nza_, p_, nzc_)
             ach = ab / (avg_dom * 1e-3) / 1e9
-            tr, tsrc = traffic_for(args.workload, dom, args.traffic_json)
+            tr, tsrc = traffic_for(wl["name"], dom, args.traffic_json)
             roof = {"bound": "hbm", "kernel": dom, "avg_launch_ms": round(avg_dom, 4), "alg_bytes_per_launch": ab,
                     "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     # traffic: FETCH_SIZE corrected x2 as the guide prescribes for gfx950 (every fabric read request of these
@@ -479,7 +510,7 @@ def bench_spgemm(ctx, args, wl):
                 "value": round(2.0 * P / best / 1e9, 4), "unit": "GFLOP/s", "cores": int(threads),
                 "kind": "reference" if use_ref else "port",
                 "sample": (f"{'omp_CSR_SpMM (reference sources, oracle/_ref)' if use_ref else 'oracle_omp_spmm (C restatement of omp_CSR_SpMM)'} "
-                           f"on the whole {args.workload} matrix, stride 512, incl. per-thread scratch allocation as in the "
+                           f"on the whole {wl['name']} matrix, stride 512, incl. per-thread scratch allocation as in the "
                            f"reference's 4-argument wrapper, {len(times)} runs (first = warm-up), median {best * 1e3:.1f} ms; "
                            f"OpenMP threads={int(threads)} of host cpus={ncpu}"),
                 "ms": round(best * 1e3, 2)}
@@ -512,15 +543,15 @@ def bench_spgemm(ctx, args, wl):
                 emit(json.dumps(result))
                 raise SystemExit("parity gate failed")
         result["setup"] = {"generate_s": round(gen_s, 2), "host_cpus": os.cpu_count()}
-        emit(json.dumps(result))
     runner.release()
+    return result if rank == 0 else None
 
 
 # ----------------------------------------------------------------------------------------------------------------------
 # BASELINE configs[4]: the R-MCL loop
 # ----------------------------------------------------------------------------------------------------------------------
 def bench_rmcl(ctx, args, wl):
-    """A step = `iters` iterations of Mt <- prune(Mgt * Mt) from the initial Mt, device-resident (hip_rmcl_expand_prune per
+    """-> the result line as a dict (rank 0; None elsewhere).  A step = `iters` iterations of Mt <- prune(Mgt * Mt) from the initial Mt, device-resident (hip_rmcl_expand_prune per
     iteration: the product is never materialised).  value = 2 * (sum of the iterations' products) / t.
     N > 1: hip_gpuRmclIter_sharded over the library's group (host arrays in and out: the copies are inside the step)."""
     from oracle import pyoracle as po                       # graph construction (rmclInit restatement) + checker/baseline only
@@ -536,29 +567,77 @@ def bench_rmcl(ctx, args, wl):
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_large.json"))).get(f"rmcl_{m}_{wl['seed']}")
 
     if world > 1:
+        # N > 1: the resident sharded loop of the library (hip_sharded_rmcl_create / run: Mgt's row blocks and the initial Mt
+        # are uploaded once, a step = `iters` iterations on device arrays, the pruned blocks gathered over RCCL every iteration)
         from sparse_matrix_with_flops_amd.dist import library_group
         grp = library_group(ctx.local_rank)
+        job = hs.ShardedRmcl(grp, H, H)
         for _ in range(max(1, args.warmup)):
-            R = hs.gpuRmclIter_sharded(grp, iters, H, H)
+            job.run(iters)
         ctx.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            R = hs.gpuRmclIter_sharded(grp, iters, H, H)
+            final_nnz = job.run(iters)
         ctx.barrier()
         (elapsed,), _ = ctx.reduce_max_sum([time.perf_counter() - t0])
+        per_iter_nnz = job.iter_nnz()
+        # parity gate, every rank's own copy of the result (it was gathered): nnz after EVERY iteration against the
+        # reference-made summary (threshold ties move a few entries), rows sum to 1, and one sampled iteration step by step
+        # against the oracle (tests/helpers.assert_rmcl_step: equal rows, or rows that differ only in proven threshold ties)
+        ok, why = True, ""
+        if not args.no_verify:
+            final = job.result(0)
+            rs = np.add.reduceat(final.values.astype(np.float64), final.rowPtr[:-1][np.diff(final.rowPtr) > 0])
+            ok = bool(np.allclose(rs, 1.0, atol=1e-5)) and int(final.nnz) == final_nnz
+            why = "" if ok else "rows of the final Mt do not sum to 1"
+            if ok and gold:
+                for it_, n_ in enumerate(per_iter_nnz):
+                    g_ = gold["per_iter"][it_]["nnz"]
+                    if abs(n_ - g_) > 5e-4 * g_ + 4096:
+                        ok, why = False, f"nnz after iteration {it_ + 1}: {n_} vs reference {g_}"
+                        break
+            if ok and rank == 0:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from helpers import assert_rmcl_step
+                k_ = min(iters, 7)                                       # a late iteration: a small product for the CPU oracle
+                job.run(k_ - 1)
+                before = job.result(0)
+                job.run(k_)
+                after = job.result(0)
+                try:
+                    assert_rmcl_step(po.CSRHost(after.rowPtr, after.colInd, after.values, m, m), Mt,
+                                     po.CSRHost(before.rowPtr, before.colInd, before.values, m, m), what=f"iteration {k_} over {world} GPUs")
+                except AssertionError as e:
+                    ok, why = False, f"iteration {k_} differs from the oracle's step: {str(e)[:300]}"
+            elif ok:                                                     # the other ranks run the same two loops (collectives)
+                k_ = min(iters, 7)
+                job.run(k_ - 1)
+                job.run(k_)
+        ok_all = ctx.all_ok(ok)
+        result = None
         if rank == 0:
-            # products per iteration: the reference-made summary holds nnz of the raw products, not P; the 1-GPU run reports P
             ms = elapsed * 1e3 / args.steps
-            emit(json.dumps({
-                "metric": "R-MCL loop wall time (host arrays in/out)", "value": round(ms, 3), "unit": "ms", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": False,
+            Ptot = sum(p_["P"] for p_ in gold["per_iter"][:iters]) if gold and "P" in gold["per_iter"][0] else None
+            result = {
+                "metric": "R-MCL loop wall time (operands resident, hip_sharded_rmcl_run)", "value": round(ms, 3), "unit": "ms",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": False,
                 "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": wl["desc"], "name": args.workload, "m": m, "iterations": iters,
-                           "parallelism": f"Mgt row-sharded by flops over {world} GPUs, Mt replicated, pruned blocks gathered "
-                                          "every iteration (hip_gpuRmclIter_sharded; host arrays in/out inside the step)"},
-                "final_nnz": int(R.nnz), "golden_final_nnz": (gold["per_iter"][iters - 1]["nnz"] if gold else None)}))
+                "config": {"workload": wl["desc"], "name": wl["name"], "m": m, "iterations": iters,
+                           "parallelism": f"Mgt row-sharded by flops over {world} GPUs, Mt replicated, pruned blocks packed into "
+                                          "their slice of the next Mt and gathered over RCCL every iteration; device-resident"},
+                "GFLOPs": (round(2.0 * Ptot / (ms * 1e-3) / 1e9, 3) if Ptot else None),
+                "per_iteration_nnz": per_iter_nnz, "final_nnz": int(final_nnz),
+                "golden_final_nnz": (gold["per_iter"][iters - 1]["nnz"] if gold else None),
+                "parity": ("ok (nnz after every iteration within the threshold-tie drift of the reference summary; rows sum to 1; "
+                           "one iteration checked step by step against the oracle)" if ok_all else f"FAILED: {why}"),
+                "roofline": None, "cpu_baseline": None}
+        job.close()
         grp.close()
-        return
+        if not ok_all:
+            if rank == 0:
+                emit(json.dumps(result))
+            raise SystemExit("parity gate failed")
+        return result
 
     h = hs.Handle(0)
     h.selftest()
@@ -622,7 +701,8 @@ def bench_rmcl(ctx, args, wl):
         for _ in range(nh):
             R_ = hs.gpuRmclIter(iters, H, H)
         host_api = {"entry": "hip_gpuRmclIter (gpuRmclIter, nlibs/gpus/gpu_csr_kernel.cu:281-311): host arrays in and out",
-                    "ms": round((time.perf_counter() - t2) * 1e3 / nh, 3), "final_nnz": int(R_.nnz)}
+                    "ms": round((time.perf_counter() - t2) * 1e3 / nh, 3), "final_nnz": int(R_.nnz),
+                    "devices_used": int(hs.lib().spgemm_hip_rmcl_devices_used())}
 
     # algorithmic bytes of one fused iteration: read A (= Mgt) and the gathered B entries, write only what survives the prune
     nnzA = int(Mt.nnz)
@@ -639,7 +719,7 @@ def bench_rmcl(ctx, args, wl):
         "value": round(2.0 * P_total / (ms_per_step * 1e-3) / 1e9, 3), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": wl["desc"], "name": args.workload, "m": m, "nnz_Mt0": nnzA, "iterations": iters,
+        "config": {"workload": wl["desc"], "name": wl["name"], "m": m, "nnz_Mt0": nnzA, "iterations": iters,
                    "products_per_step": P_total, "parallelism": "single GPU"},
         "loop_one_call_per_iteration_ms": round(per_call_ms, 3),
         "host_api": host_api,
@@ -686,8 +766,8 @@ def bench_rmcl(ctx, args, wl):
                                       "sample": f"seqRmclIter restatement, first iteration only ({per[0]['P']} products), {dt * 1e3:.0f} ms",
                                       "ms": round(dt * 1e3, 1)}
     result["setup"] = {"generate_s": round(gen_s, 2), "host_cpus": os.cpu_count()}
-    emit(json.dumps(result))
     h.close()
+    return result
 
 
 def main():
@@ -705,6 +785,11 @@ def main():
                     help="N>1, torch.distributed exchange: sub-blocks per rank whose exchange overlaps the next one's numeric phase")
     ap.add_argument("--torch-exchange", action="store_true",
                     help="N>1: exchange through torch.distributed (dist.py) instead of the library's own RCCL group")
+    ap.add_argument("--allow-torch-exchange", action="store_true",
+                    help="N>1: if the library's group cannot be made or its first step fails, fall back to the torch.distributed "
+                         "exchange instead of stopping (default: stop -- an N>1 number has one provenance)")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="default workload, N=1: skip the short runs of the other BASELINE configs attached as other_workloads")
     ap.add_argument("--traffic-json", default=None, help="profiles/*.json with PMC-derived HBM bytes per kernel")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one GPU per rank).  gloo: rehearsal of the N>1 path on a box with fewer GPUs "
@@ -715,11 +800,32 @@ def main():
     os.environ.setdefault("OMP_NUM_THREADS", str(os.cpu_count() or 1))   # cpu_baseline: all host threads
     protect_stdout()
     ctx = Ctx(args)
-    wl = WORKLOADS[args.workload]
-    if wl.get("gen") == "rmcl":
-        bench_rmcl(ctx, args, wl)
-    else:
-        bench_spgemm(ctx, args, wl)
+
+    def run(name, a):
+        wl = dict(WORKLOADS[name], name=name)
+        return bench_rmcl(ctx, a, wl) if wl.get("gen") == "rmcl" else bench_spgemm(ctx, a, wl)
+
+    result = run(args.workload, args)
+    if args.workload == "synth_1m_16" and ctx.world == 1 and not args.no_other_workloads and result is not None:
+        # The driver times ONE line: the other BASELINE configs ride on it as short runs (5 steps each, parity gate on, no
+        # cpu baseline / host-api timing), so that their numbers are the driver's measurements too and not builder claims.
+        # `value` stays the headline's.  (configs[3] = 1M/32 sharded over 2-8 GPUs is the N>1 run of this same script.)
+        import copy
+        others = {}
+        for name in ("synth_256k_16", "web_google_surrogate", "rmcl_500k"):
+            a = copy.copy(args)
+            a.steps, a.warmup, a.no_cpu_baseline, a.no_host_api = 5, 2, True, True
+            t0 = time.time()
+            r = run(name, a)
+            roof = r.get("roofline") or {}
+            others[name] = {"ms_per_step": r["ms_per_step"], "value": r["value"], "unit": r["unit"],
+                            "pipeline_frac_of_hbm_peak": r.get("pipeline_frac_of_hbm_peak"),
+                            "dominant_kernel": roof.get("kernel"), "dominant_avg_launch_ms": roof.get("avg_launch_ms"),
+                            "dominant_frac": roof.get("frac"), "parity": (r.get("parity") or "")[:160],
+                            "steps": a.steps, "wall_s": round(time.time() - t0, 1)}
+        result["other_workloads"] = others
+    if result is not None:
+        emit(json.dumps(result))
     ctx.finish()
 
 

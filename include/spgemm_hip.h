@@ -34,7 +34,7 @@ extern "C" {
 #define SPGEMM_NBINS             9
 /* reference-visible bin boundaries: hv[] as returned by gpuFlopsClassify (mindex2-cuda/flops.cu:96-107) */
 #define SPGEMM_HV_LEN            9
-#define SPGEMM_NKERNELS          20
+#define SPGEMM_NKERNELS          21
 
 typedef struct spgemm_handle spgemm_handle;
 
@@ -59,7 +59,8 @@ enum {
   SPGEMM_K_SCAN,
   SPGEMM_K_NUM_SMALL4, SPGEMM_K_NUM_G16, SPGEMM_K_NUM_HASH1, SPGEMM_K_NUM_HASH4, SPGEMM_K_NUM_HASH8, SPGEMM_K_NUM_BIG,
   SPGEMM_K_NUM_BIGHASH,
-  SPGEMM_K_CUT, SPGEMM_K_CHAIN           /* round 4: the one-pass path (cut of the rows into batches; accumulate + chained prefix) */
+  SPGEMM_K_CUT, SPGEMM_K_CHAIN,          /* round 4: rows dealt across rows -- the cut into batches; the one-pass kernel (chained prefix) */
+  SPGEMM_K_WB_SYM, SPGEMM_K_WB_NUM       /* ... and its two-pass forms (counts / entries)                                                 */
 };
 const char* spgemm_hip_kernel_name(int id);
 
@@ -261,13 +262,37 @@ spgemm_handle* hip_sharded_spmm_handle(spgemm_sharded* job, int local_shard);
 int hip_sharded_spmm_destroy(spgemm_sharded* job);
 
 /* gpuRmclIter over a group: Mgt's row blocks (cut by the flops of the first expansion) stay resident per shard, Mt is
- * replicated; every iteration a shard expands AND prunes its own rows (hip_rmcl_expand_prune), then the pruned blocks are
- * gathered into the next replicated Mt -- what crosses xGMI is the pruned matrix.  Host CSRs in, malloc()ed host CSR out
- * (every process of a multi-process group gets the whole result). */
+ * replicated; every iteration a shard expands AND prunes its own rows (the fused step), packs the kept entries straight
+ * into its slice of the next replicated Mt, and the slices are gathered -- what crosses xGMI is the pruned matrix.
+ * Host CSRs in, malloc()ed host CSR out (every process of a multi-process group gets the whole result).
+ * Replaces the one call the reference's driver makes (nlibs/gpus/gpu_csr_kernel.cu:281-311, nlibs/qrmcl.cc:149-152). */
 int hip_gpuRmclIter_sharded(spgemm_group* g, int maxIter, int rows, int cols,
                             const int* gIA, const int* gJA, const float* gA, int gnnz,
                             const int* tIA, const int* tJA, const float* tA, int tnnz,
                             int** oIA, int** oJA, float** oA, int* onnz);
+
+/* The same loop with the operands RESIDENT (round 4): create uploads Mgt's blocks and the initial Mt once; every run does
+ * maxIter iterations from that initial Mt on device arrays only (what a caller times: no upload, no download) and leaves
+ * the result on every shard; result copies it to malloc()ed host arrays; iter_nnz returns nnz(Mt) after every iteration of
+ * the last run (returns their number; at most `cap` are written).  hip_gpuRmclIter_sharded = create + run + result + destroy.
+ * A rank whose iteration fails still enters the size exchange (with a sentinel): every rank of a multi-process group
+ * leaves the run with an error instead of waiting in a collective. */
+typedef struct spgemm_sharded_rmcl spgemm_sharded_rmcl;
+int hip_sharded_rmcl_create(spgemm_group* g, int rows, int cols, const int* gIA, const int* gJA, const float* gA, int gnnz,
+                            const int* tIA, const int* tJA, const float* tA, int tnnz, spgemm_sharded_rmcl** job);
+int hip_sharded_rmcl_run(spgemm_sharded_rmcl* job, int maxIter, int* nnz);
+int hip_sharded_rmcl_result(spgemm_sharded_rmcl* job, int local_shard, int** oIA, int** oJA, float** oA, int* onnz);
+int hip_sharded_rmcl_iter_nnz(const spgemm_sharded_rmcl* job, long long* out, int cap);
+int hip_sharded_rmcl_info(const spgemm_sharded_rmcl* job, int* ends);
+int hip_sharded_rmcl_destroy(spgemm_sharded_rmcl* job);
+
+/* devices the latest hip_gpuRmclIter of this process computed on: 1 unless SPGEMM_RMCL_DEVICES=N|all (or
+ * SPGEMM_RMCL_SHARDS=K, logical shards) asked for the sharded loop -- implicit sharding is opt-in */
+int spgemm_hip_rmcl_devices_used(void);
+
+/* test hook: the next `count` symbolic phases / fused R-MCL steps on this handle fail before they queue anything (how the
+ * tests make one rank of a multi-rank group fail) */
+int spgemm_hip_debug_fail_next(spgemm_handle* h, int count);
 
 /* ---- the step in front of the path: COO -> CSR on device arrays -------------
  * Replaces COO::addSelfLoopIfNeeded (nlibs/COO.cc:160-188), COO::makeOrdered / orderedAndDuplicatesRemoving

@@ -55,6 +55,18 @@ for k in sorted(set(fetch) | set(write)):
     f_kib, w_kib = fetch.get(k, 0.0), write.get(k, 0.0)
     traffic[k] = {"fetch_KiB_raw": round(f_kib, 1), "write_KiB": round(w_kib, 1),
                   "hbm_bytes_raw": int((f_kib + w_kib) * 1024), "hbm_bytes_fetch_x2": int((2 * f_kib + w_kib) * 1024)}
-json.dump({"workload": wl, "note": "per launch averages; see header of profiles/summarize.py", "kernels": traffic},
+# provenance: the hashes of the kernel sources the profiled library was built from (its .buildinfo).  bench.py reports
+# these bytes only while the library in use was built from the same kernel sources.
+dev_sha = {}
+try:
+    lines = open(os.path.join(here, "..", "sparse_matrix_with_flops_amd", "libspgemm_hip.so.buildinfo")).read().splitlines()
+    for ln in lines[lines.index("sources sha256:") + 1:]:
+        h_, name = ln.split()
+        if name.endswith("_device.hpp"):
+            dev_sha[name] = h_
+except (OSError, ValueError):
+    pass
+json.dump({"workload": wl, "note": "per launch averages; see header of profiles/summarize.py", "kernels": traffic,
+           "device_code_sha256": dev_sha},
           open(os.path.join(here, f"{tag}_{wl}_traffic.json"), "w"), indent=1, sort_keys=True)
 print("wrote", sorted(x for x in os.listdir(here) if x.startswith(tag)))

@@ -22,6 +22,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
+#include <functional>
 #include <string>
 #include <thread>
 
@@ -98,10 +100,60 @@ struct spgemm_shard {
   int rc = 0;
 };
 
+// One worker thread per local shard, started with the first phase that has several shards to run and kept until the
+// group goes (round 3 created and joined N threads per phase: twice per R-MCL iteration, where an iteration is a
+// fraction of a millisecond per GPU).  A phase = one function run for every shard index, concurrently.
+struct ShardWorkers {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable go, done;
+  std::function<void(int)> job;
+  unsigned long long gen = 0;
+  int pending = 0;
+  bool quit = false;
+  void start(int n) {
+    for (int i = 0; i < n; ++i)
+      th.emplace_back([this, i] {
+        unsigned long long seen = 0;
+        for (;;) {
+          std::function<void(int)> fn;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            go.wait(lk, [&] { return quit || gen != seen; });
+            if (quit) return;
+            seen = gen;
+            fn = job;
+          }
+          fn(i);
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            if (--pending == 0) done.notify_all();
+          }
+        }
+      });
+  }
+  void run(int n, const std::function<void(int)>& fn) {
+    if (th.empty()) start(n);
+    std::unique_lock<std::mutex> lk(mu);
+    job = fn;
+    pending = n;
+    ++gen;
+    go.notify_all();
+    done.wait(lk, [&] { return pending == 0; });
+  }
+  void stop() {
+    { std::lock_guard<std::mutex> lk(mu); quit = true; }
+    go.notify_all();
+    for (auto& t : th) t.join();
+    th.clear();
+  }
+};
+
 struct spgemm_group {
   int nranks = 0;                                 // shards of the whole job
   int transport = SPGEMM_XCHG_PEER;
   std::vector<spgemm_shard> sh;                   // LOCAL shards (all of them in-process, one in multi-process mode)
+  ShardWorkers workers;
   bool all_local() const { return (int)sh.size() == nranks; }
 };
 
@@ -134,6 +186,7 @@ static int group_make_shards(spgemm_group* g) {
 
 extern "C" int spgemm_hip_group_destroy(spgemm_group* g) {
   if (!g) return SPGEMM_OK;
+  g->workers.stop();
   for (auto& s : g->sh) {
     hipSetDevice(s.device);
     if (s.comm && rccl().ok) rccl().CommDestroy(s.comm);
@@ -276,11 +329,7 @@ static int for_each_shard(spgemm_group* g, F&& fn) {
     s.err = s.rc ? spgemm_hip_last_error() : "";
   };
   if (n == 1) body(0);
-  else {
-    std::vector<std::thread> th;
-    for (int i = 0; i < n; ++i) th.emplace_back(body, i);
-    for (auto& t : th) t.join();
-  }
+  else g->workers.run(n, body);
   for (int i = 0; i < n; ++i)
     if (g->sh[i].rc) return fail(g->sh[i].rc, "shard %d (device %d): %s", g->sh[i].grank, g->sh[i].device, g->sh[i].err.c_str());
   return SPGEMM_OK;
@@ -310,7 +359,9 @@ static void free_csr(int device, DevCSR* c) {
 }
 
 // per-rank entry counts -> every rank knows all of them.  In-process: they are all in this process's memory.
-// Multi-process: one ncclAllGather of an int64 per rank.
+// Multi-process: one ncclAllGather of an int64 per rank.  A rank whose local phase FAILED enters the exchange all the same,
+// with -1: a rank that returned before the collective would leave every other rank waiting in it forever; this way all of
+// them see the sentinel and leave the step with an error together (any_failed below).
 static int exchange_sizes(spgemm_group* g, const std::vector<long long>& localCounts, std::vector<long long>& all) {
   all.assign((size_t)g->nranks, 0);
   if (g->all_local()) {
@@ -326,6 +377,22 @@ static int exchange_sizes(spgemm_group* g, const std::vector<long long>& localCo
   HIPCHK(hipMemcpyAsync(s.hSizes, s.dSizes, sizeof(long long) * (size_t)g->nranks, hipMemcpyDeviceToHost, s.h->stream));
   HIPCHK(hipStreamSynchronize(s.h->stream));
   for (int r = 0; r < g->nranks; ++r) all[(size_t)r] = s.hSizes[r];
+  return SPGEMM_OK;
+}
+
+static int any_failed(const std::vector<long long>& all) {
+  for (size_t r = 0; r < all.size(); ++r) if (all[r] < 0) return (int)r;
+  return -1;
+}
+// multi-process groups: one more tiny exchange before a data collective, carrying only "my part is ready" (0) or "I failed" (-1)
+static int vote_ready(spgemm_group* g, int localRc, const char* what) {
+  if (g->all_local()) return localRc;
+  const std::string msg = localRc ? spgemm_hip_last_error() : "";
+  std::vector<long long> mine(1, localRc ? -1 : 0), all;
+  CHK(exchange_sizes(g, mine, all));
+  const int bad = any_failed(all);
+  if (localRc) return fail(localRc, "%s", msg.c_str());
+  if (bad >= 0) return fail(SPGEMM_ERR_INTERNAL, "rank %d failed %s: no exchange", bad, what);
   return SPGEMM_OK;
 }
 
@@ -533,9 +600,9 @@ extern "C" int hip_sharded_spmm_step(spgemm_sharded* job, int gather, long long*
   if (!job) return fail(SPGEMM_ERR_ARG, "null job");
   spgemm_group* g = job->g;
   const int G = g->nranks;
-  std::vector<long long> localNnz(g->sh.size(), 0), all;
-  // phase 1 on every shard: classification + symbolic of its block
-  CHK(for_each_shard(g, [&](int i) -> int {
+  std::vector<long long> localNnz(g->sh.size(), -1), all;
+  // phase 1 on every shard: classification + symbolic of its block (a shard that fails keeps its -1)
+  const int rc1 = for_each_shard(g, [&](int i) -> int {
     spgemm_shard& s = g->sh[i];
     auto& L = job->loc[i];
     HIPCHK(hipSetDevice(s.device));
@@ -543,16 +610,25 @@ extern "C" int hip_sharded_spmm_step(spgemm_sharded* job, int gather, long long*
     CHK(symbolic_phase(s.h, L.A.I, L.A.J, L.A.nnz, L.B.I, L.B.J, L.A.rows, job->k, job->n, nullptr, L.lIC, &nz));
     localNnz[i] = nz;
     return SPGEMM_OK;
-  }));
-  if (gather && G > 1) CHK(exchange_sizes(g, localNnz, all));
-  else { all.assign((size_t)G, 0); for (size_t i = 0; i < g->sh.size(); ++i) all[(size_t)g->sh[i].grank] = localNnz[i]; }
+  });
+  const std::string msg1 = rc1 ? spgemm_hip_last_error() : "";
+  if (gather && G > 1 && !g->all_local()) {
+    CHK(exchange_sizes(g, localNnz, all));             // always entered: the other ranks are in it
+    if (rc1) return fail(rc1, "%s", msg1.c_str());
+    const int bad = any_failed(all);
+    if (bad >= 0) return fail(SPGEMM_ERR_INTERNAL, "rank %d failed its symbolic phase: step abandoned on every rank", bad);
+  } else {
+    if (rc1) return fail(rc1, "%s", msg1.c_str());
+    all.assign((size_t)G, 0);
+    for (size_t i = 0; i < g->sh.size(); ++i) all[(size_t)g->sh[i].grank] = localNnz[i];
+  }
   std::vector<long long> offs((size_t)G + 1, 0);
   for (int r = 0; r < G; ++r) offs[(size_t)r + 1] = offs[(size_t)r] + all[(size_t)r];
   const bool doGather = gather != 0;
   const long long total = doGather ? offs[(size_t)G] : 0;
   if (doGather && total > 0x7fffffffLL) return fail(SPGEMM_ERR_OVERFLOW, "nnz(C)=%lld does not fit int32 CSR", total);
   // phase 2: numeric straight into the shard's slice of the gathered arrays; rowPtr with the global offset
-  CHK(for_each_shard(g, [&](int i) -> int {
+  const int rc2 = for_each_shard(g, [&](int i) -> int {
     spgemm_shard& s = g->sh[i];
     auto& L = job->loc[i];
     HIPCHK(hipSetDevice(s.device));
@@ -568,7 +644,9 @@ extern "C" int hip_sharded_spmm_step(spgemm_sharded* job, int gather, long long*
     L.nnz = doGather ? total : localNnz[i];
     L.gathered = doGather;
     return SPGEMM_OK;
-  }));
+  });
+  if (doGather && G > 1) CHK(vote_ready(g, rc2, "its numeric phase"));   // (multi-process: nobody enters the allgatherv alone)
+  else if (rc2) return rc2;
   float ms = 0.f;
   for (auto& s : g->sh) ms = std::max(ms, s.h->stats.ms_total);
   job->ms_compute = ms;
@@ -625,105 +703,250 @@ extern "C" int hip_sharded_spmm_info(spgemm_sharded* job, int* ends, float* ms_c
 
 // ------------------------------------------------------------------------------------------------
 // sharded R-MCL: Mgt's row blocks stay resident per shard, Mt is replicated; per iteration every shard expands and
-// PRUNES its own rows (hip_rmcl_expand_prune), then the pruned blocks are gathered into the next replicated Mt.
+// PRUNES its own rows, then the pruned blocks are gathered into the next replicated Mt.
+//
+// Round 4: a JOB keeps the operands resident (create / run / result / destroy), so that a caller -- bench.py at N > 1 --
+// times the loop and not the upload and download around it.  An iteration on a shard is the fused step in its BLOCK form
+// (rmcl_expand_prune_core, RMCL_BLOCK: the kept entries stay in the scratch rows, their counts are scanned), one exchange
+// of the block sizes, and ONE pass that packs the scratch rows straight into the shard's slice of the next Mt
+// (k_rmcl_move; row pointers shifted by the slice's offset) -- no packed copy of the block, no device-to-device copies, no
+// per-iteration allocation once the two Mt buffers have grown to size -- and the allgatherv.  Waits per iteration: the
+// size of the block (the host needs it for the exchange) and the end of the allgatherv.
 // ------------------------------------------------------------------------------------------------
+struct spgemm_sharded_rmcl {
+  spgemm_group* g = nullptr;
+  int rows = 0, cols = 0;
+  std::vector<int> ends;
+  struct MtBuf { int* I = nullptr; int* J = nullptr; float* V = nullptr; size_t cap = 0; int nnz = 0; };
+  struct Local {
+    DevCSR Mg;                                    // this shard's row block of Mgt
+    DevCSR Mt0;                                   // replica of the initial Mt (every run starts from it)
+    MtBuf buf[2];                                 // the replicated Mt of the current / next iteration
+    // one iteration's block, between its two phases
+    int* sI = nullptr; int* sPtr = nullptr; int* sJ = nullptr; float* sV = nullptr;   // scratch rows + packed row pointer
+    bool packed = false;                          // the step gave up on the fused form: (sI, sJ, sV) is a packed block
+    int kept = 0;
+  };
+  std::vector<Local> loc;
+  int cur = -1;                                   // buf index holding the result of the last run, -1 = the initial Mt
+  std::vector<long long> iterNnz;                 // nnz(Mt) after every iteration of the last run
+};
+
+static void rmcl_release_block(spgemm_sharded_rmcl::Local& L) {
+  pool().release(L.sI); pool().release(L.sPtr); pool().release(L.sJ); pool().release(L.sV);
+  L.sI = L.sPtr = L.sJ = nullptr; L.sV = nullptr; L.packed = false; L.kept = 0;
+}
+
+extern "C" int hip_sharded_rmcl_destroy(spgemm_sharded_rmcl* job) {
+  if (!job) return SPGEMM_OK;
+  for (size_t i = 0; i < job->loc.size(); ++i) {
+    const int dev = job->g->sh[i].device;
+    auto& L = job->loc[i];
+    free_csr(dev, &L.Mg);
+    free_csr(dev, &L.Mt0);
+    hipSetDevice(dev);
+    hipStreamSynchronize(job->g->sh[i].h->stream);
+    rmcl_release_block(L);
+    for (auto& b : L.buf) { pool().release(b.I); pool().release(b.J); pool().release(b.V); }
+  }
+  delete job;
+  return SPGEMM_OK;
+}
+
+extern "C" int hip_sharded_rmcl_create(spgemm_group* g, int rows, int cols, const int* gIA, const int* gJA, const float* gA,
+                                       int gnnz, const int* tIA, const int* tJA, const float* tA, int tnnz,
+                                       spgemm_sharded_rmcl** out) {
+  if (!out) return fail(SPGEMM_ERR_ARG, "job out-pointer is null");
+  *out = nullptr;
+  if (!g) return fail(SPGEMM_ERR_ARG, "null group");
+  if (rows < 0 || cols != rows) return fail(SPGEMM_ERR_ARG, "R-MCL needs a square matrix");
+  CHK(check_common(gIA, gJA, gA, gnnz, "Mgt"));
+  CHK(check_common(tIA, tJA, tA, tnnz, "Mt"));
+  CHK(validate_host_csr(gIA, gJA, rows, cols, gnnz, "Mgt"));
+  CHK(validate_host_csr(tIA, tJA, rows, cols, tnnz, "Mt"));
+  spgemm_sharded_rmcl* job = new spgemm_sharded_rmcl();
+  job->g = g; job->rows = rows; job->cols = cols;
+  // the cut: flops of the first expansion (the blocks stay where they are for all iterations)
+  std::vector<long long> prefix;
+  host_row_flops_prefix(gIA, gJA, tIA, rows, prefix);
+  equal_partition64(prefix, g->nranks, job->ends);
+  job->loc.resize(g->sh.size());
+  int rc = for_each_shard(g, [&](int i) -> int {
+    spgemm_shard& s = g->sh[i];
+    CHK(upload_csr(s.device, gIA, gJA, gA, job->ends[s.grank], job->ends[s.grank + 1], cols, &job->loc[i].Mg));
+    CHK(upload_csr(s.device, tIA, tJA, tA, 0, rows, cols, &job->loc[i].Mt0));
+    return SPGEMM_OK;
+  });
+  if (rc) { hip_sharded_rmcl_destroy(job); return rc; }
+  *out = job;
+  return SPGEMM_OK;
+}
+
+static int rmcl_ensure_buf(spgemm_sharded_rmcl::MtBuf& b, int rows, size_t entries) {
+  if (!b.I) HIPCHK(pool().alloc((void**)&b.I, sizeof(int) * ((size_t)rows + 1)));
+  if (entries <= b.cap && b.J) return SPGEMM_OK;
+  pool().release(b.J); pool().release(b.V);
+  b.J = nullptr; b.V = nullptr; b.cap = 0;
+  const size_t cap = entries + entries / 8 + 1024;
+  HIPCHK(pool().alloc((void**)&b.J, sizeof(int) * cap));
+  HIPCHK(pool().alloc((void**)&b.V, sizeof(float) * cap));
+  b.cap = cap;
+  return SPGEMM_OK;
+}
+
+// maxIter iterations from the initial Mt; the result stays on every shard (hip_sharded_rmcl_result brings it to the host)
+extern "C" int hip_sharded_rmcl_run(spgemm_sharded_rmcl* job, int maxIter, int* nnzOut) {
+  if (!job || maxIter < 0) return fail(SPGEMM_ERR_ARG, "null job / negative iteration count");
+  spgemm_group* g = job->g;
+  const int G = g->nranks, m = job->rows, cols = job->cols;
+  const std::vector<int>& ends = job->ends;
+  job->iterNnz.clear();
+  int cur = -1;
+  auto abandon = [&](int rc) {                     // a failed iteration: drain, give the blocks back, no result
+    const std::string msg = spgemm_hip_last_error();
+    for (size_t i = 0; i < job->loc.size(); ++i) {
+      hipSetDevice(g->sh[i].device);
+      hipStreamSynchronize(g->sh[i].h->stream);
+      rmcl_release_block(job->loc[i]);
+    }
+    job->cur = -1;
+    return fail(rc, "%s", msg.c_str());
+  };
+  for (int it = 0; it < maxIter; ++it) {
+    std::vector<long long> localNnz(g->sh.size(), -1), all;
+    // phase A: expand + prune of the shard's rows, kept entries left in the scratch rows, their counts scanned
+    const int rcA = for_each_shard(g, [&](int i) -> int {
+      spgemm_shard& s = g->sh[i];
+      auto& L = job->loc[i];
+      HIPCHK(hipSetDevice(s.device));
+      const int* bI = cur < 0 ? L.Mt0.I : L.buf[cur].I;
+      const int* bJ = cur < 0 ? L.Mt0.J : L.buf[cur].J;
+      const float* bV = cur < 0 ? L.Mt0.V : L.buf[cur].V;
+      const int bn = cur < 0 ? L.Mt0.nnz : L.buf[cur].nnz;
+      int2* se = nullptr;
+      CHK(rmcl_expand_prune_core(s.h, L.Mg.I, L.Mg.J, L.Mg.V, L.Mg.nnz, bI, nullptr, nullptr, bJ, bV, bn, L.Mg.rows, cols, cols,
+                                 RMCL_BLOCK, &L.sI, &L.sPtr, &se, &L.sJ, &L.sV, &L.kept));
+      L.packed = L.sPtr == nullptr;               // (no rows / no products / product too large: a packed block came back)
+      localNnz[i] = L.kept;
+      return SPGEMM_OK;
+    });
+    const std::string msgA = rcA ? spgemm_hip_last_error() : "";
+    if (!g->all_local()) {
+      if (int rc = exchange_sizes(g, localNnz, all)) return abandon(rc);   // always entered: the other ranks are in it
+      if (rcA) { fail(rcA, "%s", msgA.c_str()); return abandon(rcA); }
+      const int bad = any_failed(all);
+      if (bad >= 0) { fail(SPGEMM_ERR_INTERNAL, "rank %d failed iteration %d: loop abandoned on every rank", bad, it); return abandon(SPGEMM_ERR_INTERNAL); }
+    } else {
+      if (rcA) { fail(rcA, "%s", msgA.c_str()); return abandon(rcA); }
+      all.assign((size_t)G, 0);
+      for (size_t i = 0; i < g->sh.size(); ++i) all[(size_t)g->sh[i].grank] = localNnz[i];
+    }
+    std::vector<long long> offs((size_t)G + 1, 0);
+    for (int r = 0; r < G; ++r) offs[(size_t)r + 1] = offs[(size_t)r] + all[(size_t)r];
+    const long long total = offs[(size_t)G];
+    if (total > 0x7fffffffLL) { fail(SPGEMM_ERR_OVERFLOW, "nnz(Mt)=%lld does not fit int32 CSR", total); return abandon(SPGEMM_ERR_OVERFLOW); }
+    const int nxt = cur < 0 ? 0 : 1 - cur;
+    std::vector<GatherView> view(g->sh.size());
+    // phase B: the block packed straight into its slice of the next Mt, row pointers shifted by the slice's offset
+    const int rcB = for_each_shard(g, [&](int i) -> int {
+      spgemm_shard& s = g->sh[i];
+      auto& L = job->loc[i];
+      HIPCHK(hipSetDevice(s.device));
+      auto& N = L.buf[nxt];
+      CHK(rmcl_ensure_buf(N, m, (size_t)std::max<long long>(total, 1)));
+      N.nnz = (int)total;
+      const long long off = offs[(size_t)s.grank];
+      const int ml = L.Mg.rows;
+      const int cnt = ml + (s.grank == G - 1 ? 1 : 0);
+      hipStream_t st = s.h->stream;
+      clear_stale_hip_error();
+      const int* ptr = L.packed ? L.sI : L.sPtr;      // row pointer of the packed block (ml + 1 entries)
+      if (cnt > 0) hipLaunchKernelGGL(k_offset_copy, dim3(cdiv(cnt, 256)), dim3(256), 0, st, cnt, ptr, (int)off, N.I + ends[s.grank]);
+      if (L.kept > 0) {
+        if (L.packed) {
+          HIPCHK(hipMemcpyAsync(N.J + off, L.sJ, sizeof(int) * (size_t)L.kept, hipMemcpyDeviceToDevice, st));
+          HIPCHK(hipMemcpyAsync(N.V + off, L.sV, sizeof(float) * (size_t)L.kept, hipMemcpyDeviceToDevice, st));
+        } else if ((long long)L.kept >= 96ll * ml) {
+          hipLaunchKernelGGL(k_rmcl_move<64>, dim3(clampi(cdiv(ml, 4), 1, s.h->numCU * 32)), dim3(256), 0, st, ml, L.sI, L.sPtr,
+                             L.sJ, L.sV, N.J + off, N.V + off);
+        } else {
+          hipLaunchKernelGGL(k_rmcl_move<16>, dim3(clampi(cdiv(ml, 16), 1, s.h->numCU * 16)), dim3(256), 0, st, ml, L.sI, L.sPtr,
+                             L.sJ, L.sV, N.J + off, N.V + off);
+        }
+      }
+      HIPCHK(hipGetLastError());
+      // RCCL runs on this same stream, behind the move; the other transports read the slice from other streams
+      if (g->transport != SPGEMM_XCHG_RCCL) HIPCHK(hipStreamSynchronize(st));
+      view[i] = GatherView{N.I, N.J, N.V};
+      return SPGEMM_OK;
+    });
+    if (int rc = vote_ready(g, rcB, "to place its block")) return abandon(rc);
+    if (G > 1 || g->transport == SPGEMM_XCHG_RCCL) {
+      if (int rc = allgatherv_segments(g, ends, offs, m, view)) return abandon(rc);   // returns with every stream drained
+    } else {
+      for (auto& s : g->sh) { hipSetDevice(s.device); if (hipStreamSynchronize(s.h->stream) != hipSuccess) { fail(SPGEMM_ERR_HIP, "sharded R-MCL: iteration %d", it); return abandon(SPGEMM_ERR_HIP); } }
+    }
+    for (auto& L : job->loc) rmcl_release_block(L);   // the streams are idle: the scratch blocks go back to the pool
+    cur = nxt;
+    job->iterNnz.push_back(total);
+  }
+  job->cur = cur;
+  if (nnzOut) *nnzOut = cur < 0 ? job->loc[0].Mt0.nnz : job->loc[0].buf[cur].nnz;
+  return SPGEMM_OK;
+}
+
+// nnz(Mt) after every iteration of the last run (the per-iteration check of bench.py against the reference-made summary)
+extern "C" int hip_sharded_rmcl_iter_nnz(const spgemm_sharded_rmcl* job, long long* out, int cap) {
+  if (!job || (cap > 0 && !out)) return fail(SPGEMM_ERR_ARG, "null argument");
+  const int n = (int)job->iterNnz.size();
+  for (int i = 0; i < n && i < cap; ++i) out[i] = job->iterNnz[(size_t)i];
+  return n;
+}
+
+extern "C" int hip_sharded_rmcl_info(const spgemm_sharded_rmcl* job, int* ends) {
+  if (!job) return fail(SPGEMM_ERR_ARG, "null job");
+  if (ends) for (size_t i = 0; i < job->ends.size(); ++i) ends[i] = job->ends[i];
+  return SPGEMM_OK;
+}
+
+// the result of the last run as held by local shard `local_shard`: malloc()ed host arrays (every shard holds the whole Mt)
+extern "C" int hip_sharded_rmcl_result(spgemm_sharded_rmcl* job, int local_shard, int** oIA, int** oJA, float** oA, int* onnz) {
+  if (!job || !oIA || !oJA || !oA || !onnz) return fail(SPGEMM_ERR_ARG, "null argument");
+  if (local_shard < 0 || local_shard >= (int)job->loc.size()) return fail(SPGEMM_ERR_ARG, "local shard %d out of range", local_shard);
+  auto& L = job->loc[(size_t)local_shard];
+  HIPCHK(hipSetDevice(job->g->sh[(size_t)local_shard].device));
+  const int* dI = job->cur < 0 ? L.Mt0.I : L.buf[job->cur].I;
+  const int* dJ = job->cur < 0 ? L.Mt0.J : L.buf[job->cur].J;
+  const float* dV = job->cur < 0 ? L.Mt0.V : L.buf[job->cur].V;
+  const int nz = job->cur < 0 ? L.Mt0.nnz : L.buf[job->cur].nnz;
+  const int rows = job->rows;
+  int* hI = (int*)malloc(sizeof(int) * ((size_t)rows + 1));
+  int* hJ = (int*)malloc(sizeof(int) * (size_t)std::max(nz, 1));
+  float* hA = (float*)malloc(sizeof(float) * (size_t)std::max(nz, 1));
+  if (!hI || !hJ || !hA) { free(hI); free(hJ); free(hA); return fail(SPGEMM_ERR_NOMEM, "host malloc failed"); }
+  if (hipMemcpy(hI, dI, sizeof(int) * ((size_t)rows + 1), hipMemcpyDeviceToHost) != hipSuccess ||
+      (nz && hipMemcpy(hJ, dJ, sizeof(int) * (size_t)nz, hipMemcpyDeviceToHost) != hipSuccess) ||
+      (nz && hipMemcpy(hA, dV, sizeof(float) * (size_t)nz, hipMemcpyDeviceToHost) != hipSuccess)) {
+    free(hI); free(hJ); free(hA);
+    return fail(SPGEMM_ERR_HIP, "copy of Mt to the host failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  *oIA = hI; *oJA = hJ; *oA = hA; *onnz = nz;
+  return SPGEMM_OK;
+}
+
+// gpuRmclIter over a group, host arrays in and out (nlibs/gpus/gpu_csr_kernel.cu:281-311): create + run + result + destroy
 extern "C" int hip_gpuRmclIter_sharded(spgemm_group* g, int maxIter, int rows, int cols,
                                        const int* gIA, const int* gJA, const float* gA, int gnnz,
                                        const int* tIA, const int* tJA, const float* tA, int tnnz,
                                        int** oIA, int** oJA, float** oA, int* onnz) {
   if (!oIA || !oJA || !oA || !onnz) return fail(SPGEMM_ERR_ARG, "output pointer is null");
-  if (!g) return fail(SPGEMM_ERR_ARG, "null group");
-  if (rows < 0 || cols != rows || maxIter < 0) return fail(SPGEMM_ERR_ARG, "R-MCL needs a square matrix and maxIter >= 0");
-  CHK(check_common(gIA, gJA, gA, gnnz, "Mgt"));
-  CHK(check_common(tIA, tJA, tA, tnnz, "Mt"));
-  CHK(validate_host_csr(gIA, gJA, rows, cols, gnnz, "Mgt"));
-  CHK(validate_host_csr(tIA, tJA, rows, cols, tnnz, "Mt"));
-  const int G = g->nranks, m = rows;
-  // the cut: flops of the first expansion (the blocks stay where they are for all iterations)
-  std::vector<long long> prefix;
-  host_row_flops_prefix(gIA, gJA, tIA, m, prefix);
-  std::vector<int> ends;
-  equal_partition64(prefix, G, ends);
-  struct Local { DevCSR Mg; DevCSR Mt; int* pI = nullptr; int* pJ = nullptr; float* pV = nullptr; int pn = 0; };
-  std::vector<Local> loc(g->sh.size());
-  auto cleanup = [&](int rc) {
-    for (size_t i = 0; i < loc.size(); ++i) {
-      const int dev = g->sh[i].device;
-      free_csr(dev, &loc[i].Mg); free_csr(dev, &loc[i].Mt);
-      hipSetDevice(dev);
-      pool().release(loc[i].pI); pool().release(loc[i].pJ); pool().release(loc[i].pV);
-    }
-    return rc;
-  };
-  int rc = for_each_shard(g, [&](int i) -> int {
-    spgemm_shard& s = g->sh[i];
-    CHK(upload_csr(s.device, gIA, gJA, gA, ends[s.grank], ends[s.grank + 1], cols, &loc[i].Mg));
-    CHK(upload_csr(s.device, tIA, tJA, tA, 0, rows, cols, &loc[i].Mt));
-    return SPGEMM_OK;
-  });
-  if (rc) return cleanup(rc);
-  for (int it = 0; it < maxIter; ++it) {
-    std::vector<long long> localNnz(g->sh.size(), 0), all;
-    rc = for_each_shard(g, [&](int i) -> int {
-      spgemm_shard& s = g->sh[i];
-      Local& L = loc[i];
-      HIPCHK(hipSetDevice(s.device));
-      CHK(hip_rmcl_expand_prune(s.h, L.Mg.I, L.Mg.J, L.Mg.V, L.Mg.nnz, L.Mt.I, L.Mt.J, L.Mt.V, L.Mt.nnz,
-                                L.Mg.rows, cols, cols, &L.pI, &L.pJ, &L.pV, &L.pn));
-      localNnz[i] = L.pn;
-      return SPGEMM_OK;
-    });
-    if (rc) return cleanup(rc);
-    if ((rc = exchange_sizes(g, localNnz, all))) return cleanup(rc);
-    std::vector<long long> offs((size_t)G + 1, 0);
-    for (int r = 0; r < G; ++r) offs[(size_t)r + 1] = offs[(size_t)r] + all[(size_t)r];
-    const long long total = offs[(size_t)G];
-    if (total > 0x7fffffffLL) return cleanup(fail(SPGEMM_ERR_OVERFLOW, "nnz(Mt)=%lld does not fit int32 CSR", total));
-    std::vector<GatherView> view(g->sh.size());
-    rc = for_each_shard(g, [&](int i) -> int {          // the next Mt: own pruned block in place, global row offsets
-      spgemm_shard& s = g->sh[i];
-      Local& L = loc[i];
-      HIPCHK(hipSetDevice(s.device));
-      DevCSR N;
-      N.rows = rows; N.cols = cols; N.nnz = (int)total;
-      HIPCHK(pool().alloc((void**)&N.I, sizeof(int) * ((size_t)m + 1)));
-      HIPCHK(pool().alloc((void**)&N.J, sizeof(int) * (size_t)std::max<long long>(total, 1)));
-      HIPCHK(pool().alloc((void**)&N.V, sizeof(float) * (size_t)std::max<long long>(total, 1)));
-      const long long off = offs[(size_t)s.grank];
-      const int cnt = L.Mg.rows + (s.grank == G - 1 ? 1 : 0);
-      clear_stale_hip_error();
-      if (cnt > 0) hipLaunchKernelGGL(k_offset_copy, dim3(cdiv(cnt, 256)), dim3(256), 0, s.h->stream, cnt, L.pI, (int)off, N.I + ends[s.grank]);
-      if (L.pn > 0) {
-        HIPCHK(hipMemcpyAsync(N.J + off, L.pJ, sizeof(int) * (size_t)L.pn, hipMemcpyDeviceToDevice, s.h->stream));
-        HIPCHK(hipMemcpyAsync(N.V + off, L.pV, sizeof(float) * (size_t)L.pn, hipMemcpyDeviceToDevice, s.h->stream));
-      }
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipStreamSynchronize(s.h->stream));
-      pool().release(L.pI); pool().release(L.pJ); pool().release(L.pV);
-      L.pI = L.pJ = nullptr; L.pV = nullptr;
-      free_csr(s.device, &L.Mt);
-      L.Mt = N;
-      view[i] = GatherView{N.I, N.J, N.V};
-      return SPGEMM_OK;
-    });
-    if (rc) return cleanup(rc);
-    if (G > 1 || g->transport == SPGEMM_XCHG_RCCL)
-      if ((rc = allgatherv_segments(g, ends, offs, m, view))) return cleanup(rc);
-  }
-  // every shard holds the whole Mt; the first local one brings it to the host
-  Local& L0 = loc[0];
-  if (hipSetDevice(g->sh[0].device) != hipSuccess) return cleanup(fail(SPGEMM_ERR_HIP, "hipSetDevice failed"));
-  const int nz = L0.Mt.nnz;
-  int* hI = (int*)malloc(sizeof(int) * ((size_t)rows + 1));
-  int* hJ = (int*)malloc(sizeof(int) * (size_t)std::max(nz, 1));
-  float* hA = (float*)malloc(sizeof(float) * (size_t)std::max(nz, 1));
-  if (!hI || !hJ || !hA) { free(hI); free(hJ); free(hA); return cleanup(fail(SPGEMM_ERR_NOMEM, "host malloc failed")); }
-  if (hipMemcpy(hI, L0.Mt.I, sizeof(int) * ((size_t)rows + 1), hipMemcpyDeviceToHost) != hipSuccess ||
-      (nz && hipMemcpy(hJ, L0.Mt.J, sizeof(int) * (size_t)nz, hipMemcpyDeviceToHost) != hipSuccess) ||
-      (nz && hipMemcpy(hA, L0.Mt.V, sizeof(float) * (size_t)nz, hipMemcpyDeviceToHost) != hipSuccess)) {
-    free(hI); free(hJ); free(hA);
-    return cleanup(fail(SPGEMM_ERR_HIP, "copy of Mt to the host failed: %s", hipGetErrorString(hipGetLastError())));
-  }
-  *oIA = hI; *oJA = hJ; *oA = hA; *onnz = nz;
-  return cleanup(SPGEMM_OK);
+  if (maxIter < 0) return fail(SPGEMM_ERR_ARG, "R-MCL needs maxIter >= 0");
+  spgemm_sharded_rmcl* job = nullptr;
+  CHK(hip_sharded_rmcl_create(g, rows, cols, gIA, gJA, gA, gnnz, tIA, tJA, tA, tnnz, &job));
+  int rc = hip_sharded_rmcl_run(job, maxIter, nullptr);
+  if (!rc) rc = hip_sharded_rmcl_result(job, 0, oIA, oJA, oA, onnz);
+  const std::string msg = rc ? spgemm_hip_last_error() : "";
+  hip_sharded_rmcl_destroy(job);
+  if (rc) return fail(rc, "%s", msg.c_str());
+  return SPGEMM_OK;
 }

@@ -180,7 +180,8 @@ struct spgemm_handle {
   int2* sbl = nullptr;                       // per A entry {B-row start, B-row length} (k_entry_lens), cap_nnz entries
   int* batchStart = nullptr;                 // one-pass path: first row of every batch (3*cap_m + 64 entries)
   unsigned long long* chainWords = nullptr;  // ... and the batches' words of the chained prefix
-  bool useChain = true;                      // SPGEMM_CHAIN=0: the two-pass pipeline for every row
+  int pathMode = 0;                          // SPGEMM_PATH: 0 per-row kernels for every row (rounds 1-3); 1 rows up to smallMax
+                                             // products through the wave-per-batch kernels, two passes; 2 the same in ONE pass
   int chainCfg = 0;                          // SPGEMM_CHAIN_CFG: kernel geometry (experiments)
   long long cap_nnz = -1;
   HostMirror* dsmall = nullptr;
@@ -212,6 +213,7 @@ struct spgemm_handle {
   int h1sym = 32;                    // blocks per CU of the wave-per-row symbolic kernel (SPGEMM_H1SYM, experiments)
   spgemm_stats stats;
   spgemm_host_api_stats host_api = {};   // phases of the latest hip_CSR_SpMM
+  int failNext = 0;                  // test hook (spgemm_hip_debug_fail_next): the next symbolic phase / R-MCL step on this handle fails
   int prev_m = -1;                   // shape and sizes of the previous one-shot SpGEMM (allocation policy of the next one)
   unsigned long long prev_P = 0;
   long long prev_nnzC = -1;
@@ -291,7 +293,7 @@ extern "C" int spgemm_hip_create(spgemm_handle** out, int device) {
   { const char* e = getenv("SPGEMM_H1SYM"); if (e) { const int c = atoi(e); if (c >= 1 && c <= 32) h->h1sym = c; } }
   { const char* e = getenv("SPGEMM_BHMARGIN"); if (e) { const int c = atoi(e); if (c >= 10 && c <= 400) h->bhMargin = c; } }
   { const char* e = getenv("SPGEMM_BHCAP"); if (e) { const int c = atoi(e); if (c >= 1024 && c <= BH_CAP_MAX) h->bhCap = c; } }
-  { const char* e = getenv("SPGEMM_CHAIN"); if (e) h->useChain = e[0] != '0'; }
+  { const char* e = getenv("SPGEMM_PATH"); if (e) { const int v = atoi(e); if (v >= 0 && v <= 2) h->pathMode = v; } }
   { const char* e = getenv("SPGEMM_CHAIN_CFG"); if (e) h->chainCfg = atoi(e); }
   { const char* e = getenv("SPGEMM_U"); if (e) { const int u = atoi(e); if (u == 2 || u == 4 || u == 8) h->U = u; } }
   for (auto& st : h->side) {
@@ -347,6 +349,14 @@ extern "C" int spgemm_hip_get_stats(const spgemm_handle* h, spgemm_stats* out) {
 }
 
 extern "C" void* spgemm_hip_stream(spgemm_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+// test hook: the next `count` symbolic phases / fused R-MCL steps on this handle return SPGEMM_ERR_INTERNAL before they queue
+// anything (how the tests make ONE rank of a multi-rank group fail: every rank must then leave the step with an error)
+extern "C" int spgemm_hip_debug_fail_next(spgemm_handle* h, int count) {
+  if (!h) return fail(SPGEMM_ERR_ARG, "null handle");
+  h->failNext = count;
+  return SPGEMM_OK;
+}
 
 extern "C" int spgemm_hip_set_kernel_timing(spgemm_handle* h, unsigned mask) {
   if (!h) return fail(SPGEMM_ERR_ARG, "null handle");
@@ -435,6 +445,10 @@ extern "C" int spgemm_hip_memcpy_d2d(void* dst, const void* src, size_t bytes) {
 // the last error of ANY earlier HIP call, ours or another library's in this process (RCCL probing devices leaves
 // "invalid device ordinal" behind: seen as a spurious failure of the next SpGEMM).  Every launch sequence therefore
 // starts by emptying the slot.
+// What this can hide: a NON-sticky error left by this library's own previous launch on the thread (a bad launch
+// configuration) if that launch site did not look at it.  Every launch sequence here ends with HIPCHK(hipGetLastError())
+// before its function returns, so there is no such site -- keep it that way: the post-launch check is mandatory wherever
+// this call opens a sequence.  Sticky errors (a fault) are not cleared by reading them and still fail the next call.
 static inline void clear_stale_hip_error() { (void)hipGetLastError(); }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline int clampi(long long v, int lo, int hi) { return (int)std::max<long long>(lo, std::min<long long>(v, hi)); }
@@ -445,7 +459,7 @@ static const char* kKernelNames[SPGEMM_NKERNELS] = {
     "k_row_flops", "k_bin_scan", "k_scatter_rows", "k_sym_g16<32,1>", "k_sym_g16", "k_sym_hash<1,1024>",
     "k_sym_hash<4,4096>", "k_sym_hash<8,8192>", "k_sym_big", "k_scan(3 launches)", "k_num_g16<32,1>", "k_num_g16",
     "k_num_hash<1,1024>", "k_num_hash<4,4096>", "k_num_hash<8,8192>", "k_num_big", "k_num_bighash", "k_cut(3 launches)",
-    "k_chain", ""};
+    "k_chain", "k_wbatch<sym>", "k_wbatch<num>"};
 extern "C" const char* spgemm_hip_kernel_name(int id) { return (id >= 0 && id < SPGEMM_NKERNELS) ? kKernelNames[id] : ""; }
 
 // every launch is bracketed by two events on its stream (per-kernel durations for bench.py's roofline)
@@ -528,7 +542,7 @@ static int launch_classify(spgemm_handle* h, const int* dIA, const int* dJA, con
 // symbolic pass over bins 2..8 (bins 0/1 were preset by K1).  Bin sizes are not known on the host
 // here (no sync): grids are capped by the CU count and every block strides / dequeues over its bin.
 static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJB,
-                           int m, int n, const int* rowIds, int* dIC, int minBin = 0) {
+                           int m, int n, const int* rowIds, int* dIC, int minBin = 0, bool skipH1A = false) {
   const int2* sbl = h->sbl;
   if (m <= 0) return SPGEMM_OK;
   clear_stale_hip_error();
@@ -549,6 +563,7 @@ static int launch_symbolic(spgemm_handle* h, const int* dIA, const int* dJB,
              sbl, dJB, h->rowFlops, dIC, err, qc + 2 * 32); }
   if (minBin <= 5) { hipStream_t st = h->side[1]; KTimer t(h, SPGEMM_K_SYM_HASH1, st);
     const int* sb = h->dsmall->slotBase;         // bin 5 = two layout slots: table 512 up to 256 products, 1024 above
+    if (!skipH1A)
     LAUNCH_U(k_sym_hash, 1, 512, dim3(grid8(m, cu * h->h1sym)), dim3(64), st, sb, SLOT_H1A, rowIds, dIA,
              sbl, dJB, h->rowFlops, dIC, err, qc + 3 * 32);
     LAUNCH_U(k_sym_hash, 1, 1024, dim3(grid8(m, cu * h->h1sym)), dim3(64), st, sb, SLOT_H1B, rowIds, dIA,
@@ -578,7 +593,8 @@ static int launch_scan(spgemm_handle* h, int* cnt, int m, unsigned long long* dT
 
 static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
                           const int* dJB, const float* dB, int n, const int* rowIds, const int* hostBinPtr,
-                          const int* dIC, int* dJC, float* dC, int* pcnt = nullptr, int pmode = 1, int minBin = 0) {
+                          const int* dIC, int* dJC, float* dC, int* pcnt = nullptr, int pmode = 1, int minBin = 0,
+                          bool skipH1A = false) {
   // pcnt != nullptr: fused R-MCL prune -- every row leaves only its kept, normalised entries at the front of its range
   // of dJC/dC and their count in pcnt[row] (rows of bin 8 are written in full and fixed up in place right behind).
   // pmode 2: no symbolic pass ran below bin 8: dIC holds the prefix sums of the rows' product counts there, exact counts
@@ -627,7 +643,7 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
     const int* sb = h->dsmall->slotBase;
     const int* hs_ = h->mirror.slotBase;
     const int na = hs_[SLOT_H1A + 1] - hs_[SLOT_H1A], nb = hs_[SLOT_H1B + 1] - hs_[SLOT_H1B];
-    if (na > 0) LAUNCH_NUM(1, 512, dim3(grid8(na, cu * 24)), dim3(64), st, sb, SLOT_H1A,
+    if (na > 0 && !skipH1A) LAUNCH_NUM(1, 512, dim3(grid8(na, cu * 24)), dim3(64), st, sb, SLOT_H1A,
                          rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7 * 32, h->rowFlops);
     if (nb > 0) LAUNCH_NUM(1, 1024, dim3(grid8(nb, cu * 16)), dim3(64), st, sb, SLOT_H1B,
                          rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7 * 32, h->rowFlops); }
@@ -650,61 +666,63 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
   return SPGEMM_OK;
 }
 
-// ---- the one-pass path (chain_device.hpp)
-// geometry: waves per block, pool slots, rows per batch, blocks per CU; rows up to smallMax products share batches, rows
-// up to rmax are a batch of their own, rows beyond (bins >= minBin of the old layout) keep their two kernels
-struct ChainCfg { int nw, pool, rb, bpc, smallMax, rmax, minBin; };
+// ---- rows up to smallMax products dealt across rows (chain_device.hpp): wave-per-batch kernels
+// geometry: waves per block, table slots per wave, blocks per CU; rows up to smallMax products go through k_wbatch, the
+// bins from minBin on keep their per-row kernels (skipH1A: of bin 5 only the 257-512 slot)
+struct ChainCfg { int nw, tbl, bpc, smallMax, minBin; bool skipH1A; };
 static const ChainCfg kChainCfgs[] = {
-    {8, 4352, 256, 3, 512, 2048, 7},
-    {12, 6912, 256, 2, 768, 2048, 7},
-    {16, 8192, 256, 1, 1024, 4096, 8},
-    {8, 7680, 256, 2, 1024, 2048, 7},
-    {8, 7680, 256, 2, 2048, 2048, 7},       // 4: no solo class: every row up to 2048 products shares windows of 3584 slots
-    {16, 8192, 256, 1, 2048, 2048, 7},      // 5: the same on one 16-wave block per CU
-    {12, 6912, 256, 2, 1536, 1536, 7},      // 6 (rows above 1536 products: not handled -> needs rmax on a bin edge; experiment only)
+    {4, 1280, 3, 512, 6, false},
+    {6, 1280, 2, 512, 6, false},
+    {4, 1024, 3, 256, 5, true},
+    {4, 2048, 2, 512, 6, false},
+    {8, 1280, 1, 512, 6, false},
 };
 static const ChainCfg& chain_cfg(const spgemm_handle* h) {
   const int n = (int)(sizeof(kChainCfgs) / sizeof(kChainCfgs[0]));
   return kChainCfgs[h->chainCfg >= 0 && h->chainCfg < n ? h->chainCfg : 0];
 }
+#ifndef SMF_WB_MAXR
+#define SMF_WB_MAXR 8
+#endif
 
 static int launch_cut(spgemm_handle* h, int m) {
   const ChainCfg& c = chain_cfg(h);
   const int ntiles = std::max(1, cdiv(m, SCAN_TILE));
-  const CutParams p{c.smallMax, c.rmax, c.pool - 2 * c.smallMax, c.rb};
+  const CutParams p{c.smallMax, c.tbl - wb_slots(c.smallMax), WAVE};
   clear_stale_hip_error();
   KTimer t(h, SPGEMM_K_CUT);
   hipLaunchKernelGGL(k_cut_sums, dim3(ntiles), dim3(SCAN_THREADS), 0, h->stream, m, h->rowFlops, p, h->tileSum);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, h->stream, ntiles, h->tileSum, &h->dsmall->cutTotal);
   hipLaunchKernelGGL(k_cut_apply, dim3(ntiles), dim3(SCAN_THREADS), 0, h->stream, m, h->rowFlops, p, h->tileSum,
-                     h->batchStart, h->chainWords, &h->dsmall->nBatches);
+                     h->batchStart, h->chainWords, &h->dsmall->nBatches, &h->dsmall->chainTicket);
   HIPCHK(hipGetLastError());
   return SPGEMM_OK;
 }
 
-template <int NW, int POOL, int RB>
-static void launch_chain_t(spgemm_handle* h, int blocks, int m, const int* dIA, const float* dA, const int* dJB, const float* dB,
-                           int rmax, int* dIC, int* dJC, float* dC, long long capC) {
-  typedef ChainShared<NW, POOL, RB> Sh;
+template <int NW, int TBL, int MODE>
+static void launch_wbatch_t(spgemm_handle* h, int blocks, int m, const int* dIA, const float* dA, const int* dJB, const float* dB,
+                            int smallMax, int* dIC, int* dJC, float* dC, long long capC) {
+  typedef WaveBatchShared<NW, TBL> Sh;
   static bool attr = false;                              // (more than 64 KB of dynamic LDS needs the attribute once)
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_chain<NW, POOL, RB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Sh)); attr = true; }
-  hipLaunchKernelGGL((k_chain<NW, POOL, RB, 2>), dim3(blocks), dim3(WAVE * NW), sizeof(Sh), h->stream, m, dIA, h->sbl, dA, dJB, dB,
-                     h->rowFlops, rmax, h->batchStart, &h->dsmall->nBatches, h->chainWords, &h->dsmall->chainTicket, dIC, dJC, dC,
+  if (!attr) { (void)hipFuncSetAttribute((const void*)k_wbatch<NW, TBL, MODE, SMF_WB_MAXR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Sh)); attr = true; }
+  hipLaunchKernelGGL((k_wbatch<NW, TBL, MODE, SMF_WB_MAXR>), dim3(blocks), dim3(WAVE * NW), sizeof(Sh), h->stream, m, dIA, h->sbl, dA, dJB, dB,
+                     h->rowFlops, smallMax, h->batchStart, &h->dsmall->nBatches, h->chainWords, &h->dsmall->chainTicket, dIC, dJC, dC,
                      capC, &h->dsmall->nnzC64, &h->dsmall->err);
 }
 
-static int launch_chain(spgemm_handle* h, int m, const int* dIA, const float* dA, const int* dJB, const float* dB,
-                        int* dIC, int* dJC, float* dC, long long capC) {
+template <int MODE>
+static int launch_wbatch(spgemm_handle* h, int m, const int* dIA, const float* dA, const int* dJB, const float* dB,
+                         int* dIC, int* dJC, float* dC, long long capC) {
   const ChainCfg& c = chain_cfg(h);
   clear_stale_hip_error();
-  KTimer t(h, SPGEMM_K_CHAIN);
+  KTimer t(h, MODE == WB_SYM ? SPGEMM_K_WB_SYM : MODE == WB_NUM ? SPGEMM_K_WB_NUM : SPGEMM_K_CHAIN);
   const int blocks = clampi((long long)h->numCU * c.bpc, 1, 1 << 20);
   switch (h->chainCfg) {
-    case 1: launch_chain_t<12, 6912, 256>(h, blocks, m, dIA, dA, dJB, dB, c.rmax, dIC, dJC, dC, capC); break;
-    case 2: launch_chain_t<16, 8192, 256>(h, blocks, m, dIA, dA, dJB, dB, c.rmax, dIC, dJC, dC, capC); break;
-    case 3: case 4: launch_chain_t<8, 7680, 256>(h, blocks, m, dIA, dA, dJB, dB, c.rmax, dIC, dJC, dC, capC); break;
-    case 5: launch_chain_t<16, 8192, 256>(h, blocks, m, dIA, dA, dJB, dB, c.rmax, dIC, dJC, dC, capC); break;
-    default: launch_chain_t<8, 4352, 256>(h, blocks, m, dIA, dA, dJB, dB, c.rmax, dIC, dJC, dC, capC); break;
+    case 1: launch_wbatch_t<6, 1280, MODE>(h, blocks, m, dIA, dA, dJB, dB, c.smallMax, dIC, dJC, dC, capC); break;
+    case 2: launch_wbatch_t<4, 1024, MODE>(h, blocks, m, dIA, dA, dJB, dB, c.smallMax, dIC, dJC, dC, capC); break;
+    case 3: launch_wbatch_t<4, 2048, MODE>(h, blocks, m, dIA, dA, dJB, dB, c.smallMax, dIC, dJC, dC, capC); break;
+    case 4: launch_wbatch_t<8, 1280, MODE>(h, blocks, m, dIA, dA, dJB, dB, c.smallMax, dIC, dJC, dC, capC); break;
+    default: launch_wbatch_t<4, 1280, MODE>(h, blocks, m, dIA, dA, dJB, dB, c.smallMax, dIC, dJC, dC, capC); break;
   }
   HIPCHK(hipGetLastError());
   return SPGEMM_OK;
@@ -726,6 +744,7 @@ static int unpack_classification(spgemm_handle* h, int m, const PreClass& pre, i
 static int symbolic_phase(spgemm_handle* h, const int* dIA, const int* dJA, int nnzA, const int* dIB, const int* dJB,
                           int m, int k, int n, const PreClass* pre, int* dIC, int* nnzCp) {
   (void)k;
+  if (h->failNext > 0) { --h->failNext; return fail(SPGEMM_ERR_INTERNAL, "forced failure (spgemm_hip_debug_fail_next)"); }
   hipStream_t s = h->stream;
   hipEventRecord(h->ev[0], s);
   h->cur_rowIds = h->rowIds;
@@ -832,16 +851,19 @@ static int spgemm_device(spgemm_handle* h, const int* dIA, const int* dJA, const
     h->cur_rowIds = h->rowIds;
     int rc = launch_classify(h, dIA, dJA, dIB, m, nnzA, dIC);
     if (rc) return cleanup(rc);
-    // One-pass path (chain_device.hpp, round 4): the rows up to ChainCfg::rmax products are accumulated and placed by ONE
-    // kernel (no symbolic pass, no scan); only the bins above keep their symbolic + numeric kernels.
-    const bool chainPath = h->useChain;
-    const int minBin = chainPath ? chain_cfg(h).minBin : 0;
-    if (chainPath && (rc = launch_cut(h, m))) return cleanup(rc);
+    // Rows up to ChainCfg::smallMax products are dealt across rows by the wave-per-batch kernels (chain_device.hpp, round 4):
+    // pathMode 1 in two passes (counts, scan, entries), pathMode 2 in ONE pass (no symbolic pass and no scan for them: a chained
+    // prefix over the batches places them); the bins above keep their per-row kernels.
+    const bool chainPath = h->pathMode == 2, wb2 = h->pathMode == 1;
+    const int minBin = (chainPath || wb2) ? chain_cfg(h).minBin : 0;
+    const bool skipH1A = (chainPath || wb2) && chain_cfg(h).skipH1A;
+    if ((chainPath || wb2) && (rc = launch_cut(h, m))) return cleanup(rc);
     hipEventRecord(h->ev[1], s);
     if (hipMemcpyAsync(h->hmid, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipEventRecord(h->evMid, s) != hipSuccess)
       return cleanup(fail(SPGEMM_ERR_HIP, "classification copy failed: %s", hipGetErrorString(hipGetLastError())));
-    if ((rc = launch_symbolic(h, dIA, dJB, m, n, h->cur_rowIds, dIC, minBin))) return cleanup(rc);
+    if (wb2 && (rc = launch_wbatch<WB_SYM>(h, m, dIA, nullptr, dJB, nullptr, dIC, nullptr, nullptr, 0))) return cleanup(rc);
+    if ((rc = launch_symbolic(h, dIA, dJB, m, n, h->cur_rowIds, dIC, minBin, skipH1A))) return cleanup(rc);
     hipEventRecord(h->ev[2], s);
     if (!chainPath && (rc = launch_scan(h, dIC, m, &h->dsmall->nnzC64))) return cleanup(rc);
     hipEventRecord(h->ev[3], s);
@@ -863,8 +885,9 @@ static int spgemm_device(spgemm_handle* h, const int* dIA, const int* dJA, const
         return cleanup(fail(SPGEMM_ERR_HIP, "device allocation of C (%llu entries) failed", P));
       hipEventRecord(h->ev[4], s);
       h->mirror = mid;                                 // bin sizes for the numeric launch grids
-      if (chainPath && (rc = launch_chain(h, m, dIA, dA, dJB, dB, dIC, dJC, dC, (long long)capC))) return cleanup(rc);
-      if (P > 0 && (rc = launch_numeric(h, dIA, dA, dJB, dB, n, h->cur_rowIds, mid.binPtr, dIC, dJC, dC, nullptr, 1, minBin))) return cleanup(rc);
+      if (chainPath && (rc = launch_wbatch<WB_CHAIN>(h, m, dIA, dA, dJB, dB, dIC, dJC, dC, (long long)capC))) return cleanup(rc);
+      if (wb2 && P > 0 && (rc = launch_wbatch<WB_NUM>(h, m, dIA, dA, dJB, dB, dIC, dJC, dC, (long long)capC))) return cleanup(rc);
+      if (P > 0 && (rc = launch_numeric(h, dIA, dA, dJB, dB, n, h->cur_rowIds, mid.binPtr, dIC, dJC, dC, nullptr, 1, minBin, skipH1A))) return cleanup(rc);
       hipEventRecord(h->ev[5], s);
       if (hipMemcpyAsync(h->hsmall, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess ||
           hipStreamSynchronize(s) != hipSuccess)
@@ -1458,16 +1481,23 @@ static int rmcl_pack_rows(spgemm_handle* h, int m, const int* starts, const int*
 // One R-MCL iteration (expansion with the row rule fused into the numeric epilogues) on device arrays.
 //   dIBlen != nullptr   B is NOT packed: row j is [dIB[j], dIB[j] + dIBlen[j]) of (dJB, dB), dIBse[j] holds the same
 //                       extent as one {start, end} pair (what the classification gathers); nnzB = the arrays' extent
-//   pack == false       the result is left where the epilogues wrote it: *dIN = the scratch row starts (m + 1 entries),
+//   mode RMCL_EXTENTS   the result is left where the epilogues wrote it: *dIN = the scratch row starts (m + 1 entries),
 //                       *dLenN = the kept entries per row, *dSEN = the {start, end} pairs, *dJN / *dCN = the scratch
 //                       arrays, *nnzN = their extent (P).
 //                       The next iteration reads it as its unpacked B: no scan, no copy, no allocation of packed arrays.
+//   mode RMCL_BLOCK     (sharded loop) the rows stay in the scratch arrays too, but their lengths are scanned: *dIN = the
+//                       scratch row starts, *dLenN = the row pointer of the PACKED block (m + 1 entries, [m] = *nnzN =
+//                       kept entries), *dJN / *dCN = the scratch arrays.  The caller packs the rows wherever the block
+//                       belongs (its slice of the next replicated Mt: k_rmcl_move), with no packed copy in between.
 //                       (The paths that give up on the fused step return a packed result and *dLenN = nullptr.)
+enum { RMCL_EXTENTS = 0, RMCL_PACK = 1, RMCL_BLOCK = 2 };
 static int rmcl_expand_prune_core(spgemm_handle* h, const int* dIA, const int* dJA, const float* dA, int nnzA,
                                   const int* dIB, const int* dIBlen, const int2* dIBse, const int* dJB, const float* dB,
-                                  int nnzB, int m, int k, int n, bool pack, int** dIN, int** dLenN, int2** dSEN,
+                                  int nnzB, int m, int k, int n, int mode, int** dIN, int** dLenN, int2** dSEN,
                                   int** dJN, float** dCN, int* nnzN, bool* errPending = nullptr) {
+  const bool pack = mode == RMCL_PACK;
   *dIN = nullptr; *dLenN = nullptr; *dSEN = nullptr; *dJN = nullptr; *dCN = nullptr; *nnzN = 0;
+  if (h->failNext > 0) { --h->failNext; return fail(SPGEMM_ERR_INTERNAL, "forced failure (spgemm_hip_debug_fail_next)"); }
   HIPCHK(hipSetDevice(h->device));
   auto two_steps = [&]() {                           // no rows, no products, or a product too large for the scratch C
     int *bI = nullptr, *bJ = nullptr, bn = nnzB;
@@ -1487,6 +1517,9 @@ static int rmcl_expand_prune_core(spgemm_handle* h, const int* dIA, const int* d
   CHK(ws_ensure(h, m));
   int* dIC = nullptr; int* cnt = nullptr; int* dJC = nullptr; float* dC = nullptr; int* JN = nullptr; float* CN = nullptr;
   auto cleanup = [&](int rc) {
+    // a failure may leave kernels queued that still write these blocks (and, in the loop form, the previous iteration's):
+    // the pool hands a released block to other handles and streams, so nothing goes back before the stream has drained
+    if (rc) (void)hipStreamSynchronize(h->stream);
     for (void* q : {(void*)dIC, (void*)cnt, (void*)dJC, (void*)dC, (void*)JN, (void*)CN}) pool().release(q);
     return rc;
   };
@@ -1549,10 +1582,10 @@ static int rmcl_expand_prune_core(spgemm_handle* h, const int* dIA, const int* d
   h->mirror = mid;
   if ((rc = launch_numeric(h, dIA, dA, dJB, dB, n, h->cur_rowIds, mid.binPtr, dIC, dJC, dC, cnt, nosym ? 2 : 1))) return cleanup(rc);
   hipEventRecord(h->ev[5], s);
-  if (pack && (rc = launch_scan(h, cnt, m, &h->dsmall->kept64))) return cleanup(rc);
+  if ((pack || mode == RMCL_BLOCK) && (rc = launch_scan(h, cnt, m, &h->dsmall->kept64))) return cleanup(rc);
   if (hipMemcpyAsync(h->hsmall, h->dsmall, sizeof(HostMirror), hipMemcpyDeviceToHost, s) != hipSuccess)
     return hipfail("numeric phase");
-  if (!pack && errPending && h->ktiming == 0) {
+  if (mode == RMCL_EXTENTS && errPending && h->ktiming == 0) {
     // Loop form: nothing of this iteration is needed on the host before the next one starts -- its classification is
     // queued behind the numeric kernels, and the error flags are looked at after that classification's event (above).
     // The host runs ahead and the GPU does not idle between iterations.  (With per-kernel timing on, the events have to
@@ -1584,6 +1617,10 @@ static int rmcl_expand_prune_core(spgemm_handle* h, const int* dIA, const int* d
   hipEventElapsedTime(&st.ms_total, h->ev[0], h->ev[5]);
   collect_kernel_times(h, true);
   grow_bitmaps(h, n);
+  if (mode == RMCL_BLOCK) {                          // scratch rows + the row pointer of the packed block
+    *dIN = dIC; *dLenN = cnt; *dJN = dJC; *dCN = dC; *nnzN = (int)hm.kept64;
+    return SPGEMM_OK;
+  }
   if (!pack) {                                       // the rows stay where the epilogues wrote them
     int2* se = nullptr;
     if (hipSuccess != pool().alloc((void**)&se, sizeof(int2) * (size_t)m)) return hipfail("device allocation failed");
@@ -1619,7 +1656,7 @@ extern "C" int hip_rmcl_expand_prune(spgemm_handle* h, const int* dIA, const int
   if (!h) CHK(default_handle(&h));
   int* len = nullptr;
   int2* se = nullptr;
-  return rmcl_expand_prune_core(h, dIA, dJA, dA, nnzA, dIB, nullptr, nullptr, dJB, dB, nnzB, m, k, n, true, dIN, &len, &se,
+  return rmcl_expand_prune_core(h, dIA, dJA, dA, nnzA, dIB, nullptr, nullptr, dJB, dB, nnzB, m, k, n, RMCL_PACK, dIN, &len, &se,
                                 dJN, dCN, nnzN);
 }
 
@@ -1662,8 +1699,8 @@ extern "C" int hip_gpuRmclIter_device(spgemm_handle* h, int maxIter, int rows, i
     int2* nSE = nullptr;
     float* nV = nullptr;
     const bool pack = keep_packed || it == maxIter - 1;
-    const int rc = rmcl_expand_prune_core(h, dgI, dgJ, dgA, gnnz, bI, bLen, bSE, bJ, bV, bn, rows, cols, cols, pack, &nI,
-                                          &nLen, &nSE, &nJ, &nV, &nn, &errPending);
+    const int rc = rmcl_expand_prune_core(h, dgI, dgJ, dgA, gnnz, bI, bLen, bSE, bJ, bV, bn, rows, cols, cols,
+                                          pack ? RMCL_PACK : RMCL_EXTENTS, &nI, &nLen, &nSE, &nJ, &nV, &nn, &errPending);
     if (rc) return bail(rc);
     flush_old();                                     // the call above waited behind the kernels that read these
     drop();                                          // the Mt it read itself: released after the next call
@@ -1688,6 +1725,12 @@ extern "C" int hip_gpuRmclIter_device(spgemm_handle* h, int maxIter, int rows, i
 }
 
 struct spgemm_group;
+static std::mutex g_rmcl_group_mu;                     // the group hip_gpuRmclIter keeps between calls (same device layout)
+static spgemm_group* g_rmcl_group = nullptr;
+static std::vector<int> g_rmcl_group_devs;
+static int g_rmcl_devices_used = 1;
+// devices the latest hip_gpuRmclIter of this process computed on (1 unless SPGEMM_RMCL_DEVICES asked for more)
+extern "C" int spgemm_hip_rmcl_devices_used(void) { return g_rmcl_devices_used; }
 extern "C" int spgemm_hip_group_create(spgemm_group** out, int nshards, const int* devices, int transport);
 extern "C" int spgemm_hip_group_destroy(spgemm_group* g);
 extern "C" int hip_gpuRmclIter_sharded(spgemm_group* g, int maxIter, int rows, int cols, const int* gIA, const int* gJA,
@@ -1704,26 +1747,35 @@ extern "C" int hip_gpuRmclIter(int maxIter, int rows, int cols, const int* gIA, 
   CHK(validate_host_csr(gIA, gJA, rows, cols, gnnz, "Mgt"));
   CHK(validate_host_csr(tIA, tJA, rows, cols, tnnz, "Mt"));
   {
-    // More than one device visible: Mgt's rows are cut into flops-balanced blocks, one per GPU, Mt is replicated and the
-    // pruned blocks are gathered every iteration (sharded.hpp) -- behind the same call the reference's driver makes
-    // (nlibs/qrmcl.cc:149-152).  SPGEMM_RMCL_DEVICES limits the devices used; SPGEMM_RMCL_SHARDS asks for that many
-    // LOGICAL shards (spread round-robin over the devices: the one-GPU rehearsal of the sharded loop).
+    // Several devices, when the caller asks for them: Mgt's rows are cut into flops-balanced blocks, one per GPU, Mt is
+    // replicated and the pruned blocks are gathered every iteration (sharded.hpp) -- behind the same call the reference's
+    // driver makes (nlibs/qrmcl.cc:149-152).  OPT-IN (round 3 sharded over every visible device by default: a 100-row graph
+    // was cut over 8 GPUs, and a process-per-GPU job would have opened contexts and communicators on all of them from every
+    // rank): SPGEMM_RMCL_DEVICES=N|all uses N devices (0..N-1); SPGEMM_RMCL_SHARDS=K asks for K LOGICAL shards spread
+    // round-robin over those devices (the one-GPU rehearsal of the sharded loop).  Unset: one device, the default handle's.
+    // The group is kept for the next call with the same layout (the C++ mirror's --stats mode calls this once per iteration:
+    // handles, RCCL communicators and pinned buffers are made once).
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
-    int use = ndev;
-    if (const char* e = getenv("SPGEMM_RMCL_DEVICES")) use = std::max(1, std::min(ndev, atoi(e)));
+    int use = 1;
+    if (const char* e = getenv("SPGEMM_RMCL_DEVICES")) use = !strcasecmp(e, "all") ? ndev : std::max(1, std::min(ndev, atoi(e)));
     int shards = use;
     if (const char* e = getenv("SPGEMM_RMCL_SHARDS")) shards = std::max(1, std::min(64, atoi(e)));
+    g_rmcl_devices_used = 1;
     if (shards > 1 && rows >= shards) {
       std::vector<int> devs((size_t)shards);
       for (int i = 0; i < shards; ++i) devs[(size_t)i] = i % std::max(use, 1);
-      spgemm_group* grp = nullptr;
-      int rc = spgemm_hip_group_create(&grp, shards, devs.data(), SPGEMM_XCHG_AUTO);
-      if (rc == SPGEMM_OK) {
-        rc = hip_gpuRmclIter_sharded(grp, maxIter, rows, cols, gIA, gJA, gA, gnnz, tIA, tJA, tA, tnnz, oIA, oJA, oA, onnz);
-        spgemm_hip_group_destroy(grp);
+      std::lock_guard<std::mutex> lk(g_rmcl_group_mu);
+      int rc = SPGEMM_OK;
+      if (!g_rmcl_group || g_rmcl_group_devs != devs) {
+        if (g_rmcl_group) { spgemm_hip_group_destroy(g_rmcl_group); g_rmcl_group = nullptr; }
+        rc = spgemm_hip_group_create(&g_rmcl_group, shards, devs.data(), SPGEMM_XCHG_AUTO);
+        if (rc == SPGEMM_OK) g_rmcl_group_devs = devs;
+        else g_rmcl_group = nullptr;
       }
-      if (rc == SPGEMM_OK) return rc;
+      if (rc == SPGEMM_OK)
+        rc = hip_gpuRmclIter_sharded(g_rmcl_group, maxIter, rows, cols, gIA, gJA, gA, gnnz, tIA, tJA, tA, tnnz, oIA, oJA, oA, onnz);
+      if (rc == SPGEMM_OK) { g_rmcl_devices_used = std::min(use, shards); return rc; }
       // the caller asked for an R-MCL result, not for a particular number of GPUs: say what went wrong and carry on with one
       fprintf(stderr, "hip_gpuRmclIter: the %d-shard loop failed (%s); running on one device\n", shards, spgemm_hip_last_error());
     }

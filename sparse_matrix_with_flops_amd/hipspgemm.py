@@ -14,6 +14,7 @@ There is no CPU fallback: if the library or a HIP device is missing, calls raise
 PyTorch is not needed here; bench.py / dist.py use it only for device memory and torch.distributed.
 """
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -24,7 +25,7 @@ LIB_PATH = os.environ.get("SPGEMM_LIB") or os.path.join(_HERE, "libspgemm_hip.so
 
 NBINS = 9
 HV_LEN = 9
-NKERNELS = 20
+NKERNELS = 21
 _I = C.POINTER(C.c_int)
 _F = C.POINTER(C.c_float)
 
@@ -40,6 +41,8 @@ EXPORTS = [
     "spgemm_hip_group_destroy", "hip_sharded_spmm_create", "hip_sharded_spmm_step", "hip_sharded_spmm_result",
     "hip_sharded_spmm_info", "hip_sharded_spmm_destroy", "hip_gpuRmclIter_sharded", "spgemm_hip_host_api_stats",
     "hip_sharded_spmm_handle", "spgemm_hip_rccl_available", "spgemm_hip_pool_trim",
+    "hip_sharded_rmcl_create", "hip_sharded_rmcl_run", "hip_sharded_rmcl_result", "hip_sharded_rmcl_iter_nnz",
+    "hip_sharded_rmcl_info", "hip_sharded_rmcl_destroy", "spgemm_hip_debug_fail_next", "spgemm_hip_rmcl_devices_used",
 ]
 XCHG_AUTO, XCHG_RCCL, XCHG_PEER, XCHG_HOST = 0, 1, 2, 3
 XCHG_NAMES = {0: "auto", 1: "rccl", 2: "peer", 3: "host"}
@@ -150,6 +153,13 @@ def lib():
         L.hip_sharded_spmm_handle.restype = C.c_void_p
         L.hip_gpuRmclIter_sharded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + host_in + host_in + \
             [C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I]
+        L.hip_sharded_rmcl_create.argtypes = [C.c_void_p, C.c_int, C.c_int] + host_in + host_in + [C.POINTER(C.c_void_p)]
+        L.hip_sharded_rmcl_run.argtypes = [C.c_void_p, C.c_int, _I]
+        L.hip_sharded_rmcl_result.argtypes = [C.c_void_p, C.c_int, C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I]
+        L.hip_sharded_rmcl_iter_nnz.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]
+        L.hip_sharded_rmcl_info.argtypes = [C.c_void_p, _I]
+        L.hip_sharded_rmcl_destroy.argtypes = [C.c_void_p]
+        L.spgemm_hip_debug_fail_next.argtypes = [C.c_void_p, C.c_int]
         L.free = C.CDLL(None).free
         L.free.argtypes = [C.c_void_p]
         _lib = L
@@ -201,6 +211,10 @@ class Handle:
     def set_kernel_timing(self, mask):
         """bit i: bracket the launches of kernel i with HIP events (stats()['ms_kernel']); 0 = none (default)."""
         _check(lib().spgemm_hip_set_kernel_timing(self._h, int(mask) & 0xFFFFFFFF), "spgemm_hip_set_kernel_timing")
+
+    def fail_next(self, count=1):
+        """test hook: the next `count` symbolic phases / fused R-MCL steps on this handle fail"""
+        _check(lib().spgemm_hip_debug_fail_next(self._h, int(count)), "spgemm_hip_debug_fail_next")
 
     def close(self):
         if self._h and self._own:
@@ -591,6 +605,10 @@ class Group:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         _check(lib().spgemm_hip_group_info(self._g, C.byref(a), C.byref(b), C.byref(c)), "spgemm_hip_group_info")
         self.nranks, self.nlocal, self.transport = a.value, b.value, c.value
+        # jobs made on this group and handles borrowed from it: the C side of a job dereferences the group when it is
+        # destroyed, and a borrowed Handle points at a handle the group owns -- close() takes them down first, in that order
+        self._jobs = weakref.WeakSet()
+        self._borrowed = weakref.WeakSet()
 
     @staticmethod
     def of_rank(nranks, rank, device, id128):
@@ -606,6 +624,10 @@ class Group:
 
     def close(self):
         if self._g:
+            for j in list(self._jobs):
+                j.close()
+            for h in list(self._borrowed):
+                h._h = C.c_void_p()                   # the handle dies with the group: a later call fails with "null argument"
             lib().spgemm_hip_group_destroy(self._g)
             self._g = C.c_void_p()
 
@@ -641,6 +663,7 @@ class ShardedSpMM:
         _check(lib().hip_sharded_spmm_create(group.ptr, *_host_args(A), *bargs, A.rows, A.cols,
                                              (B.cols if B is not None else A.cols), C.byref(self._j)), "hip_sharded_spmm_create")
         self.m, self.n = A.rows, (B.cols if B is not None else A.cols)
+        group._jobs.add(self)
 
     def step(self, gather=True):
         """-> (nnzC, total products P)"""
@@ -661,7 +684,9 @@ class ShardedSpMM:
         p = lib().hip_sharded_spmm_handle(self._j, int(local_shard))
         if not p:
             raise SpgemmError("no such local shard")
-        return Handle(_borrowed=p)
+        h = Handle(_borrowed=p)
+        self.group._borrowed.add(h)
+        return h
 
     def info(self):
         ends = (C.c_int * (self.group.nranks + 1))()
@@ -672,6 +697,56 @@ class ShardedSpMM:
     def close(self):
         if self._j:
             lib().hip_sharded_spmm_destroy(self._j)
+            self._j = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardedRmcl:
+    """spgemm_sharded_rmcl: the R-MCL loop over a Group with the operands resident (host CSRs in once; every run() starts
+    from the initial Mt and leaves the result on the shards)."""
+
+    def __init__(self, group, Mgt, Mt):
+        assert not Mgt.on_device and not Mt.on_device
+        self.group = group
+        self._keep = (Mgt, Mt)
+        self.rows, self.cols = Mt.rows, Mt.cols
+        self._j = C.c_void_p()
+        _check(lib().hip_sharded_rmcl_create(group.ptr, Mgt.rows, Mgt.cols, *_host_args(Mgt), *_host_args(Mt), C.byref(self._j)),
+               "hip_sharded_rmcl_create")
+        group._jobs.add(self)
+
+    def run(self, maxIter):
+        """-> nnz of the final Mt"""
+        n = C.c_int(0)
+        _check(lib().hip_sharded_rmcl_run(self._j, int(maxIter), C.byref(n)), "hip_sharded_rmcl_run")
+        return n.value
+
+    def iter_nnz(self):
+        buf = (C.c_longlong * 256)()
+        n = lib().hip_sharded_rmcl_iter_nnz(self._j, buf, 256)
+        return [int(buf[i]) for i in range(min(n, 256))]
+
+    def result(self, local_shard=0):
+        L = lib()
+        pi, pj, pv, n = _I(), _I(), _F(), C.c_int(0)
+        _check(L.hip_sharded_rmcl_result(self._j, int(local_shard), C.byref(pi), C.byref(pj), C.byref(pv), C.byref(n)),
+               "hip_sharded_rmcl_result")
+        rp, ci, v = _take_malloced(L, pi, pj, pv, self.rows, n.value)
+        return CSR(v, ci, rp, self.rows, self.cols, n.value)
+
+    def ends(self):
+        e = (C.c_int * (self.group.nranks + 1))()
+        _check(lib().hip_sharded_rmcl_info(self._j, e), "hip_sharded_rmcl_info")
+        return [int(x) for x in e]
+
+    def close(self):
+        if self._j:
+            lib().hip_sharded_rmcl_destroy(self._j)
             self._j = C.c_void_p()
 
     def __del__(self):

@@ -270,11 +270,15 @@ def test_cpp_mirror_runs_the_reference_test_protocol():
         assert "Differs" not in out.stdout and "Same" in out.stdout
     # nrmcl with the reference's flags (process_args.cc:12-27): --input/-i --maxIters/-m --stride --rmclOptions/-r
     exe = os.path.join(ROOT, "tests", "cpp", "nrmcl.x")
+    # ... and --shared None|Shared|L1 (process_args.cc:17,60-63; nGpuSpMM.cc:297-299): a reference command line runs unchanged
     for args in (["--input", os.path.join(DATA, "t2.snap"), "--maxIters", "3", "--stride", "128", "--rmclOptions", "GPU"],
-                 ["-i", os.path.join(DATA, "own_graph.snap"), "-m", "2", "-r", "GPU", "--stats"]):
+                 ["-i", os.path.join(DATA, "own_graph.snap"), "-m", "2", "-r", "GPU", "--stats"],
+                 ["--input", os.path.join(DATA, "t2.snap"), "--maxIters", "3", "--shared", "L1", "--rmclOptions", "GPU"]):
         out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "rmclOption= GPU" in out.stdout and "Same" in out.stdout and "Diffs" not in out.stdout
+        assert "unrecognized option" not in out.stderr
+        assert ("SharedOption= CachePreferL1" if "--shared" in args else "SharedOption= CachePreferNone") in out.stdout
         if "--stats" in args:
             assert "Total sum =" in out.stdout
     # --stats also writes the reference's per-iteration drift report, percent.stats (nlibs/qrmcl.cc:17-24,65-70): one line

@@ -101,16 +101,24 @@ def test_sharded_rmcl_steps_match_the_oracle(shards, transport):
 
 
 def test_gpuRmclIter_dispatches_to_the_sharded_loop(monkeypatch):
-    """hip_gpuRmclIter itself goes multi-shard when asked (SPGEMM_RMCL_SHARDS: logical shards on the visible devices; with
-    more than one device visible it does so on its own): same result as the single-device loop on a tie-free input."""
+    """hip_gpuRmclIter itself goes multi-shard WHEN ASKED (SPGEMM_RMCL_DEVICES=N|all: that many devices;
+    SPGEMM_RMCL_SHARDS: logical shards on them) -- opt-in since round 4: unset, it computes on one device whatever is
+    visible.  Same result as the single-device loop on a tie-free input; the group is kept between calls."""
     import os
     from helpers import DATA
     Mt = po.load(os.path.join(DATA, "own_graph.snap"), isTrans=True, mode=1)
     monkeypatch.delenv("SPGEMM_RMCL_SHARDS", raising=False)
-    monkeypatch.setenv("SPGEMM_RMCL_DEVICES", "1")
+    monkeypatch.delenv("SPGEMM_RMCL_DEVICES", raising=False)
     one = hs.gpuRmclIter(3, to_hs(Mt), to_hs(Mt))
+    assert hs.lib().spgemm_hip_rmcl_devices_used() == 1            # nothing asked for: one device
+    monkeypatch.setenv("SPGEMM_RMCL_DEVICES", "all")
+    hs.gpuRmclIter(1, to_hs(Mt), to_hs(Mt))
+    assert hs.lib().spgemm_hip_rmcl_devices_used() == hs.device_count()
+    monkeypatch.setenv("SPGEMM_RMCL_DEVICES", "1")
     monkeypatch.setenv("SPGEMM_RMCL_SHARDS", "3")
     three = hs.gpuRmclIter(3, to_hs(Mt), to_hs(Mt))
+    again = hs.gpuRmclIter(3, to_hs(Mt), to_hs(Mt))               # the cached group
+    assert np.array_equal(again.rowPtr, three.rowPtr) and np.array_equal(again.colInd, three.colInd)
     a, b = po.CSRHost(one.rowPtr, one.colInd, one.values, Mt.rows, Mt.cols), po.CSRHost(three.rowPtr, three.colInd, three.values, Mt.rows, Mt.cols)
     assert_parity(b, a, what="3 logical shards vs one device")
 
@@ -273,3 +281,113 @@ def test_rank_groups_exchange_over_a_loopback_rccl(world):
     out = subprocess.run([sys.executable, "-c", _LOOPBACK_SCRIPT.format(root=ROOT, world=world)], capture_output=True,
                          text=True, timeout=300, env=env)
     assert out.returncode == 0 and f"loopback ok {world}" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+_FAIL_SCRIPT = r"""
+import os, sys, threading, time
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from helpers import po, synth_csr
+from sparse_matrix_with_flops_amd import hipspgemm as hs
+from test_gpu_sharded_abi import _graph, to_hs_plain
+W, BAD = {world}, {bad}
+A = synth_csr(20000, 29, 2)
+Mt = _graph(9000, 37)
+ident = hs.unique_id()
+out, errs = [None] * W, []
+def rank(r):
+    try:
+        g = hs.Group.of_rank(W, r, 0, ident)
+        job = hs.ShardedSpMM(g, to_hs_plain(A))
+        job.step(gather=True)                                  # a good step first
+        if r == BAD:
+            job.handle(0).fail_next(1)                         # this rank's next symbolic phase fails before it queues anything
+        t0 = time.time()
+        try:
+            job.step(gather=True)
+            first = "no error"
+        except hs.SpgemmError as e:
+            first = str(e)
+        dt = time.time() - t0
+        nnz, _ = job.step(gather=True)                         # and the job is usable again on every rank
+        rm = hs.ShardedRmcl(g, to_hs_plain(Mt), to_hs_plain(Mt))
+        rm.run(1)
+        if r == BAD:
+            # (a handle of the group: the R-MCL job computes with the same one)
+            job.handle(0).fail_next(1)
+        try:
+            rm.run(2)
+            second = "no error"
+        except hs.SpgemmError as e:
+            second = str(e)
+        n2 = rm.run(2)
+        rm.close(); job.close(); g.close()                     # the group stays destroyable
+        out[r] = (first, dt, nnz, second, n2)
+    except BaseException as e:                                 # noqa: BLE001
+        errs.append((r, repr(e)))
+ts = [threading.Thread(target=rank, args=(r,)) for r in range(W)]
+[t.start() for t in ts]
+[t.join(120) for t in ts]
+assert not any(t.is_alive() for t in ts), "a rank is still waiting in a collective"
+assert not errs, errs
+want = po.omp_spmm(A, A).nnz
+for r in range(W):
+    first, dt, nnz, second, n2 = out[r]
+    assert first != "no error" and dt < 30.0, (r, first, dt)
+    assert ("forced failure" in first) == (r == BAD) and (r == BAD or "rank %d failed" % BAD in first), (r, first)
+    assert nnz == want
+    assert second != "no error" and (("forced failure" in second) == (r == BAD)), (r, second)
+    assert n2 == out[0][4]
+print("failure propagated", W)
+"""
+
+
+@pytest.mark.parametrize("world,bad", [(2, 1), (3, 0)])
+def test_a_failing_rank_takes_every_rank_out_of_the_step(world, bad):
+    """Round-3 review: a rank whose symbolic phase failed returned before the size exchange and left the other ranks waiting
+    in ncclAllGather forever.  Now the failing rank enters the exchange with a sentinel: EVERY rank returns an error (the
+    failing one its own, the others "rank r failed"), within a timeout, the job and the group stay usable and destroyable --
+    for the sharded SpGEMM step and for the sharded R-MCL loop.  Ranks = threads over the loopback stand-in for RCCL."""
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "libloopback_rccl.so"])
+    env = dict(os.environ, SPGEMM_RCCL_LIB=os.path.join(ROOT, "tests", "cpp", "libloopback_rccl.so"))
+    out = subprocess.run([sys.executable, "-c", _FAIL_SCRIPT.format(root=ROOT, world=world, bad=bad)], capture_output=True,
+                         text=True, timeout=400, env=env)
+    assert out.returncode == 0 and f"failure propagated {world}" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.parametrize("shards,transport", [(1, hs.XCHG_PEER), (3, hs.XCHG_PEER), (2, hs.XCHG_HOST), (1, hs.XCHG_RCCL)])
+def test_sharded_rmcl_job_keeps_its_operands_resident(shards, transport):
+    """hip_sharded_rmcl_create / run / result (round 4): the loop on device arrays only -- what bench.py times at N > 1.
+    Every run starts from the initial Mt (same result twice), every iteration is checked against the oracle's step from
+    the previous iteration's result, nnz per iteration is reported, every shard holds the whole result, and a failure inside
+    a run leaves the job usable."""
+    Mt = _graph(15000, 41)
+    g = hs.Group(shards, devices=[0] * shards, transport=transport)
+    job = hs.ShardedRmcl(g, to_hs_plain(Mt), to_hs_plain(Mt))
+    assert job.run(0) == Mt.nnz
+    r0 = job.result(0)
+    assert np.array_equal(r0.rowPtr, Mt.rowPtr) and np.array_equal(r0.colInd, Mt.colInd)
+    prev = Mt
+    for iters in (1, 2, 3):
+        n = job.run(iters)
+        cur = job.result(0)
+        assert n == cur.nnz and job.iter_nnz()[-1] == n and len(job.iter_nnz()) == iters
+        got = po.CSRHost(cur.rowPtr, cur.colInd, cur.values, Mt.rows, Mt.cols)
+        assert_rmcl_step(got, Mt, prev, what=f"iteration {iters} of the resident loop, {shards} shards")
+        prev = got
+    again = job.run(3)
+    assert again == prev.nnz
+    for s_ in range(shards):
+        rs = job.result(s_)
+        assert np.array_equal(rs.rowPtr, prev.rowPtr) and np.array_equal(rs.colInd, prev.colInd) and np.array_equal(rs.values, prev.values)
+    flops = po.row_flops(Mt, Mt)
+    prefix = np.concatenate([[0], np.cumsum(flops)]).astype(np.int64)
+    assert np.array_equal(job.ends(), po.equal_partition64(prefix, shards))
+    g.close()                                          # closes the job first (Group keeps track of what was made on it)
+    with pytest.raises(Exception):
+        job.run(1)

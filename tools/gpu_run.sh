@@ -9,7 +9,7 @@ mkdir -p gpurun_out
 mode="$1"; shift
 case "$mode" in
   tests)
-    timeout -k 10 1100 python -m pytest tests ${@:--m gpu -x -q} 2>&1 | tail -25 ;;
+    timeout -k 10 1100 python -m pytest ${@:-tests -m gpu -x -q} 2>&1 | tail -25 ;;
   bench)
     wl="$1"; shift
     timeout -k 10 500 python bench.py --workload "$wl" "$@" > gpurun_out/bench_$wl.json 2> gpurun_out/bench_$wl.err || { tail -5 gpurun_out/bench_$wl.err; exit 1; }

@@ -1,6 +1,6 @@
-"""Diagnostic: where a block of k_chain (the one-pass kernel) spends its time: wave 0, cycle stamps around the phases of a batch.
-Needs the stamped build:  make -C sparse_matrix_with_flops_amd/csrc variant VAR_NAME=stamps VAR_FLAGS=-DSMF_STAMPS
-    SPGEMM_LIB=.../libspgemm_hip_stamps.so python tools/stamps_chain.py [workload]"""
+"""Diagnostic: where a wave of k_wbatch (chain_device.hpp) spends its time: wave 0 of every block, cycle stamps around the phases
+of a batch.  Needs the stamped build:  make -C sparse_matrix_with_flops_amd/csrc variant VAR_NAME=stamps VAR_FLAGS=-DSMF_STAMPS
+    SPGEMM_PATH=1|2 SPGEMM_LIB=.../libspgemm_hip_stamps.so python tools/stamps_chain.py [workload]"""
 import ctypes as C
 import os
 import sys
@@ -27,14 +27,13 @@ for _ in range(N):
     hs.gpuSpMMWrapper(A, A, h).deviceDispose()
 assert L.spgemm_hip_debug_chain_stamps(out) == 0
 s = [int(x) for x in out]
-names = ["phase 0: rows -> regions (loads of rowFlops/IA, scans, 2 barriers)", "phase 1: the product walk (staging, gathers, inserts)",
-         "phase 2: occupancy sweep + step scan + publish", "look-back (waiting for the batches before)", "barrier after the look-back",
-         "phase 3: rowPtr + emission + clear + barrier", "-", "loop top"]
+names = ["round top: ticket (+2 barriers in chain mode)", "rows -> regions (batchStart, rowFlops, IA loads; scans)",
+         "the product walk (staging, gathers, inserts)", "occupancy sweep, step scan, ranks (sym: + IC store, clear)",
+         "chain: barrier, publish, look-back", "chain: barrier after the look-back, rowPtr", "emission + clear", "-"]
 tot = s[8]
-print(f"{wl}: {s[9] // N} blocks, {s[10] // N} batches per launch ({s[10] / max(s[9], 1):.1f} per block), "
-      f"{s[11] / max(s[10], 1):.1f} A entries per batch; wave 0 of each block: {tot / s[9] / 100e6 * 1e3:.3f} ms at 100 MHz per launch, "
-      f"{tot / max(s[10], 1) / 100.0:.2f} us per batch")
+print(f"{wl} SPGEMM_PATH={os.environ.get('SPGEMM_PATH')}: {s[9] // N} block launches; wave 0 of each: "
+      f"{tot / max(s[9], 1) / 1e3:.1f} k cycles per launch")
 for i, n in enumerate(names):
     if n != "-":
-        print(f"  {n:70s} {100.0 * s[i] / tot:5.1f} %   {s[i] / max(s[10], 1) / 100.0:6.2f} us per batch")
+        print(f"  {n:70s} {100.0 * s[i] / tot:5.1f} %")
 print(f"  {'unaccounted':70s} {100.0 * (tot - sum(s[:8])) / tot:5.1f} %")
