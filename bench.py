@@ -566,7 +566,9 @@ def bench_rmcl(ctx, args, wl):
     H = hs.CSR.from_arrays(Mt.rowPtr, Mt.colInd, Mt.values, m, m)
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_large.json"))).get(f"rmcl_{m}_{wl['seed']}")
 
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_GROUP"):
+        # (BENCH_FORCE_GROUP=1: rehearsal of this branch on one GPU -- a group of ONE rank, its block makes the round trip
+        # through the library's RCCL transport to itself)
         # N > 1: the resident sharded loop of the library (hip_sharded_rmcl_create / run: Mgt's row blocks and the initial Mt
         # are uploaded once, a step = `iters` iterations on device arrays, the pruned blocks gathered over RCCL every iteration)
         from sparse_matrix_with_flops_amd.dist import library_group

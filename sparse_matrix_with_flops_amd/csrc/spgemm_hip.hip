@@ -1182,6 +1182,7 @@ struct CopyLanes {
   static constexpr int T = 8;
   static constexpr size_t SLOT = size_t(4) << 20;
   char* slot[T][2] = {};
+  hipEvent_t done[T][2] = {};                         // "the copy out of this slot has finished" (host -> device direction)
   hipStream_t st[T] = {};
   int device = -1;
   std::mutex mu;
@@ -1190,14 +1191,21 @@ struct CopyLanes {
     release();
     for (int t = 0; t < T; ++t) {
       HIPCHK(hipStreamCreateWithFlags(&st[t], hipStreamNonBlocking));
-      for (int b = 0; b < 2; ++b) HIPCHK(hipHostMalloc((void**)&slot[t][b], SLOT, hipHostMallocDefault));
+      for (int b = 0; b < 2; ++b) {
+        HIPCHK(hipHostMalloc((void**)&slot[t][b], SLOT, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&done[t][b], hipEventDisableTiming));
+      }
     }
     device = dev;
     return SPGEMM_OK;
   }
   void release() {
     for (int t = 0; t < T; ++t) {
-      for (int b = 0; b < 2; ++b) { if (slot[t][b]) hipHostFree(slot[t][b]); slot[t][b] = nullptr; }
+      for (int b = 0; b < 2; ++b) {
+        if (slot[t][b]) hipHostFree(slot[t][b]);
+        if (done[t][b]) hipEventDestroy(done[t][b]);
+        slot[t][b] = nullptr; done[t][b] = nullptr;
+      }
       if (st[t]) hipStreamDestroy(st[t]);
       st[t] = nullptr;
     }
@@ -1207,7 +1215,8 @@ struct CopyLanes {
 CopyLanes& lanes() { static CopyLanes* l = new CopyLanes(); return *l; }
 
 // one thread's slice; toDevice: host -> device, else device -> host
-hipError_t lane_copy(int dev, hipStream_t st, char* const slots[2], char* host, char* devp, size_t bytes, bool toDevice) {
+hipError_t lane_copy(int dev, hipStream_t st, char* const slots[2], hipEvent_t const done[2], char* host, char* devp, size_t bytes,
+                     bool toDevice) {
   hipError_t e = hipSetDevice(dev);
   if (e != hipSuccess) return e;
   const size_t S = CopyLanes::SLOT;
@@ -1216,9 +1225,12 @@ hipError_t lane_copy(int dev, hipStream_t st, char* const slots[2], char* host, 
     for (size_t c = 0; c < n; ++c) {
       const size_t off = c * S, len = std::min(S, bytes - off);
       char* sl = slots[c & 1];
-      if (c >= 2 && (e = hipStreamSynchronize(st)) != hipSuccess) return e;   // (both slots' earlier copies are done)
+      // wait only for THIS slot's previous transfer (chunk c-2): chunk c-1 stays on the link while this one is staged
+      // (round 3 synchronised the stream here, which also waited for chunk c-1: the two slots gave no double buffering)
+      if (c >= 2 && (e = hipEventSynchronize(done[c & 1])) != hipSuccess) return e;
       memcpy(sl, host + off, len);
       if ((e = hipMemcpyAsync(devp + off, sl, len, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+      if ((e = hipEventRecord(done[c & 1], st)) != hipSuccess) return e;
     }
     return hipStreamSynchronize(st);
   }
@@ -1286,7 +1298,7 @@ static int copy_pageable(int dev, const CopyJob* jobs, int njobs, bool toDevice)
         const size_t b = jobs[i].bytes;
         const size_t per = ((b + CopyLanes::T - 1) / CopyLanes::T + 4095) & ~size_t(4095);
         const size_t lo = std::min(b, per * (size_t)t), hi = std::min(b, lo + per);
-        if (hi > lo) errs[t] = lane_copy(dev, L.st[t], L.slot[t], (char*)jobs[i].host + lo, (char*)jobs[i].dev + lo, hi - lo, toDevice);
+        if (hi > lo) errs[t] = lane_copy(dev, L.st[t], L.slot[t], L.done[t], (char*)jobs[i].host + lo, (char*)jobs[i].dev + lo, hi - lo, toDevice);
       }
     });
   }

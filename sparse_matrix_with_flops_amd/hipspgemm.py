@@ -181,6 +181,27 @@ def device_count():
     return n.value if rc == 0 else 0
 
 
+# Objects that own something on the C side, closed in dependency order when the interpreter exits (jobs before the groups
+# they were made on, groups before plain handles): left to the garbage collector at shutdown they are finalised in any
+# order, after the HIP runtime has started to go away -- seen as a segmentation fault at exit after a failed test.
+_LIVE = weakref.WeakSet()
+
+
+def _close_all():
+    live = list(_LIVE)
+    for kind in ("ShardedSpMM", "ShardedRmcl", "Group", "Handle"):
+        for o in live:
+            if type(o).__name__ == kind:
+                try:
+                    o.close()
+                except Exception:
+                    pass
+
+
+import atexit  # noqa: E402
+atexit.register(_close_all)
+
+
 class Handle:
     """spgemm_handle: one HIP stream + workspace on one device."""
 
@@ -191,6 +212,7 @@ class Handle:
         else:
             self._h = C.c_void_p()
             _check(lib().spgemm_hip_create(C.byref(self._h), int(device)), "spgemm_hip_create")
+            _LIVE.add(self)
         self.device = device
 
     @property
@@ -609,6 +631,7 @@ class Group:
         # destroyed, and a borrowed Handle points at a handle the group owns -- close() takes them down first, in that order
         self._jobs = weakref.WeakSet()
         self._borrowed = weakref.WeakSet()
+        _LIVE.add(self)
 
     @staticmethod
     def of_rank(nranks, rank, device, id128):
@@ -664,6 +687,7 @@ class ShardedSpMM:
                                              (B.cols if B is not None else A.cols), C.byref(self._j)), "hip_sharded_spmm_create")
         self.m, self.n = A.rows, (B.cols if B is not None else A.cols)
         group._jobs.add(self)
+        _LIVE.add(self)
 
     def step(self, gather=True):
         """-> (nnzC, total products P)"""
@@ -719,6 +743,7 @@ class ShardedRmcl:
         _check(lib().hip_sharded_rmcl_create(group.ptr, Mgt.rows, Mgt.cols, *_host_args(Mgt), *_host_args(Mt), C.byref(self._j)),
                "hip_sharded_rmcl_create")
         group._jobs.add(self)
+        _LIVE.add(self)
 
     def run(self, maxIter):
         """-> nnz of the final Mt"""
