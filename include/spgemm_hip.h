@@ -281,6 +281,7 @@ typedef struct spgemm_sharded_rmcl spgemm_sharded_rmcl;
 int hip_sharded_rmcl_create(spgemm_group* g, int rows, int cols, const int* gIA, const int* gJA, const float* gA, int gnnz,
                             const int* tIA, const int* tJA, const float* tA, int tnnz, spgemm_sharded_rmcl** job);
 int hip_sharded_rmcl_run(spgemm_sharded_rmcl* job, int maxIter, int* nnz);
+int hip_sharded_rmcl_continue(spgemm_sharded_rmcl* job, int iters, int* nnz);   /* from the previous run's result */
 int hip_sharded_rmcl_result(spgemm_sharded_rmcl* job, int local_shard, int** oIA, int** oJA, float** oA, int* onnz);
 int hip_sharded_rmcl_iter_nnz(const spgemm_sharded_rmcl* job, long long* out, int cap);
 int hip_sharded_rmcl_info(const spgemm_sharded_rmcl* job, int* ends);

@@ -794,14 +794,15 @@ static int rmcl_ensure_buf(spgemm_sharded_rmcl::MtBuf& b, int rows, size_t entri
   return SPGEMM_OK;
 }
 
-// maxIter iterations from the initial Mt; the result stays on every shard (hip_sharded_rmcl_result brings it to the host)
-extern "C" int hip_sharded_rmcl_run(spgemm_sharded_rmcl* job, int maxIter, int* nnzOut) {
+// maxIter iterations from the initial Mt (fromCurrent: from the result of the previous run -- how a caller checks ONE step of
+// a trajectory); the result stays on every shard (hip_sharded_rmcl_result brings it to the host)
+static int sharded_rmcl_run(spgemm_sharded_rmcl* job, int maxIter, int* nnzOut, bool fromCurrent) {
   if (!job || maxIter < 0) return fail(SPGEMM_ERR_ARG, "null job / negative iteration count");
   spgemm_group* g = job->g;
   const int G = g->nranks, m = job->rows, cols = job->cols;
   const std::vector<int>& ends = job->ends;
-  job->iterNnz.clear();
-  int cur = -1;
+  if (!fromCurrent) job->iterNnz.clear();
+  int cur = fromCurrent ? job->cur : -1;
   auto abandon = [&](int rc) {                     // a failed iteration: drain, give the blocks back, no result
     const std::string msg = spgemm_hip_last_error();
     for (size_t i = 0; i < job->loc.size(); ++i) {
@@ -893,6 +894,13 @@ extern "C" int hip_sharded_rmcl_run(spgemm_sharded_rmcl* job, int maxIter, int* 
   job->cur = cur;
   if (nnzOut) *nnzOut = cur < 0 ? job->loc[0].Mt0.nnz : job->loc[0].buf[cur].nnz;
   return SPGEMM_OK;
+}
+
+extern "C" int hip_sharded_rmcl_run(spgemm_sharded_rmcl* job, int maxIter, int* nnzOut) {
+  return sharded_rmcl_run(job, maxIter, nnzOut, false);
+}
+extern "C" int hip_sharded_rmcl_continue(spgemm_sharded_rmcl* job, int iters, int* nnzOut) {
+  return sharded_rmcl_run(job, iters, nnzOut, true);
 }
 
 // nnz(Mt) after every iteration of the last run (the per-iteration check of bench.py against the reference-made summary)

@@ -41,7 +41,7 @@ EXPORTS = [
     "spgemm_hip_group_destroy", "hip_sharded_spmm_create", "hip_sharded_spmm_step", "hip_sharded_spmm_result",
     "hip_sharded_spmm_info", "hip_sharded_spmm_destroy", "hip_gpuRmclIter_sharded", "spgemm_hip_host_api_stats",
     "hip_sharded_spmm_handle", "spgemm_hip_rccl_available", "spgemm_hip_pool_trim",
-    "hip_sharded_rmcl_create", "hip_sharded_rmcl_run", "hip_sharded_rmcl_result", "hip_sharded_rmcl_iter_nnz",
+    "hip_sharded_rmcl_create", "hip_sharded_rmcl_run", "hip_sharded_rmcl_continue", "hip_sharded_rmcl_result", "hip_sharded_rmcl_iter_nnz",
     "hip_sharded_rmcl_info", "hip_sharded_rmcl_destroy", "spgemm_hip_debug_fail_next", "spgemm_hip_rmcl_devices_used",
 ]
 XCHG_AUTO, XCHG_RCCL, XCHG_PEER, XCHG_HOST = 0, 1, 2, 3
@@ -155,6 +155,7 @@ def lib():
             [C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I]
         L.hip_sharded_rmcl_create.argtypes = [C.c_void_p, C.c_int, C.c_int] + host_in + host_in + [C.POINTER(C.c_void_p)]
         L.hip_sharded_rmcl_run.argtypes = [C.c_void_p, C.c_int, _I]
+        L.hip_sharded_rmcl_continue.argtypes = [C.c_void_p, C.c_int, _I]
         L.hip_sharded_rmcl_result.argtypes = [C.c_void_p, C.c_int, C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I]
         L.hip_sharded_rmcl_iter_nnz.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]
         L.hip_sharded_rmcl_info.argtypes = [C.c_void_p, _I]
@@ -745,10 +746,11 @@ class ShardedRmcl:
         group._jobs.add(self)
         _LIVE.add(self)
 
-    def run(self, maxIter):
-        """-> nnz of the final Mt"""
+    def run(self, maxIter, restart=True):
+        """maxIter iterations from the initial Mt (restart=False: from the previous run's result) -> nnz of the final Mt"""
         n = C.c_int(0)
-        _check(lib().hip_sharded_rmcl_run(self._j, int(maxIter), C.byref(n)), "hip_sharded_rmcl_run")
+        fn = lib().hip_sharded_rmcl_run if restart else lib().hip_sharded_rmcl_continue
+        _check(fn(self._j, int(maxIter), C.byref(n)), "hip_sharded_rmcl_run")
         return n.value
 
     def iter_nnz(self):

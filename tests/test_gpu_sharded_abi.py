@@ -380,6 +380,13 @@ def test_sharded_rmcl_job_keeps_its_operands_resident(shards, transport):
         got = po.CSRHost(cur.rowPtr, cur.colInd, cur.values, Mt.rows, Mt.cols)
         assert_rmcl_step(got, Mt, prev, what=f"iteration {iters} of the resident loop, {shards} shards")
         prev = got
+    job.run(2)                                         # one step of the SAME trajectory (restart=False): exact bookkeeping
+    two = job.result(0)
+    n3 = job.run(1, restart=False)
+    three = job.result(0)
+    assert n3 == three.nnz and job.iter_nnz()[-1] == n3 and len(job.iter_nnz()) == 3
+    assert_rmcl_step(po.CSRHost(three.rowPtr, three.colInd, three.values, Mt.rows, Mt.cols), Mt,
+                     po.CSRHost(two.rowPtr, two.colInd, two.values, Mt.rows, Mt.cols), what="continued run")
     again = job.run(3)
     assert again == prev.nnz
     want_c = prev.canonical()
