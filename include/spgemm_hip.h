@@ -287,6 +287,8 @@ int hip_sharded_rmcl_iter_nnz(const spgemm_sharded_rmcl* job, long long* out, in
 int hip_sharded_rmcl_info(const spgemm_sharded_rmcl* job, int* ends);
 int hip_sharded_rmcl_destroy(spgemm_sharded_rmcl* job);
 
+int spgemm_hip_handle_device(const spgemm_handle* h);   /* the device a handle (a group's shard) computes on; -1 for NULL */
+
 /* devices the latest hip_gpuRmclIter of this process computed on: 1 unless SPGEMM_RMCL_DEVICES=N|all (or
  * SPGEMM_RMCL_SHARDS=K, logical shards) asked for the sharded loop -- implicit sharding is opt-in */
 int spgemm_hip_rmcl_devices_used(void);

@@ -350,6 +350,8 @@ extern "C" int spgemm_hip_get_stats(const spgemm_handle* h, spgemm_stats* out) {
 
 extern "C" void* spgemm_hip_stream(spgemm_handle* h) { return h ? (void*)h->stream : nullptr; }
 
+extern "C" int spgemm_hip_handle_device(const spgemm_handle* h) { return h ? h->device : -1; }
+
 // test hook: the next `count` symbolic phases / fused R-MCL steps on this handle return SPGEMM_ERR_INTERNAL before they queue
 // anything (how the tests make ONE rank of a multi-rank group fail: every rank must then leave the step with an error)
 extern "C" int spgemm_hip_debug_fail_next(spgemm_handle* h, int count) {

@@ -42,7 +42,7 @@ EXPORTS = [
     "hip_sharded_spmm_info", "hip_sharded_spmm_destroy", "hip_gpuRmclIter_sharded", "spgemm_hip_host_api_stats",
     "hip_sharded_spmm_handle", "spgemm_hip_rccl_available", "spgemm_hip_pool_trim",
     "hip_sharded_rmcl_create", "hip_sharded_rmcl_run", "hip_sharded_rmcl_continue", "hip_sharded_rmcl_result", "hip_sharded_rmcl_iter_nnz",
-    "hip_sharded_rmcl_info", "hip_sharded_rmcl_destroy", "spgemm_hip_debug_fail_next", "spgemm_hip_rmcl_devices_used",
+    "hip_sharded_rmcl_info", "hip_sharded_rmcl_destroy", "spgemm_hip_debug_fail_next", "spgemm_hip_rmcl_devices_used", "spgemm_hip_handle_device",
 ]
 XCHG_AUTO, XCHG_RCCL, XCHG_PEER, XCHG_HOST = 0, 1, 2, 3
 XCHG_NAMES = {0: "auto", 1: "rccl", 2: "peer", 3: "host"}
@@ -161,6 +161,7 @@ def lib():
         L.hip_sharded_rmcl_info.argtypes = [C.c_void_p, _I]
         L.hip_sharded_rmcl_destroy.argtypes = [C.c_void_p]
         L.spgemm_hip_debug_fail_next.argtypes = [C.c_void_p, C.c_int]
+        L.spgemm_hip_handle_device.argtypes = [C.c_void_p]
         L.free = C.CDLL(None).free
         L.free.argtypes = [C.c_void_p]
         _lib = L
@@ -214,7 +215,7 @@ class Handle:
             self._h = C.c_void_p()
             _check(lib().spgemm_hip_create(C.byref(self._h), int(device)), "spgemm_hip_create")
             _LIVE.add(self)
-        self.device = device
+        self.device = device if _borrowed is None else int(lib().spgemm_hip_handle_device(self._h))
 
     @property
     def ptr(self):
