@@ -2,7 +2,7 @@
 # SQ-side counters for one workload (separate --pmc passes, kernel-trace only); summarised by tools/pmc_sq.py
 WL=${1:-synth_1m_16}
 OUT=$PWD/gpurun_out/pmc_sq; rm -rf $OUT; mkdir -p $OUT
-ARGS="$PWD/bench.py --workload $WL --steps 2 --warmup 1 --no-verify --no-cpu-baseline --no-host-api"
+ARGS="$PWD/bench.py --workload $WL --steps 2 --warmup 1 --no-verify --no-cpu-baseline --no-host-api --no-other-workloads"
 cd /tmp && export TMPDIR=/tmp
 i=0
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" \

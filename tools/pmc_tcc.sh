@@ -2,7 +2,7 @@
 # L2 / fabric-side counters for one workload (separate --pmc passes of <= 4 TCC counters, kernel-trace only)
 WL=${1:-synth_1m_16}
 OUT=$PWD/gpurun_out/pmc_tcc; rm -rf $OUT; mkdir -p $OUT
-ARGS="$PWD/bench.py --workload $WL --steps 2 --warmup 1 --no-verify --no-cpu-baseline --no-host-api"
+ARGS="$PWD/bench.py --workload $WL --steps 2 --warmup 1 --no-verify --no-cpu-baseline --no-host-api --no-other-workloads"
 cd /tmp && export TMPDIR=/tmp
 i=0
 for SET in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" \
