@@ -10,7 +10,7 @@ def load(path):
 
 
 def brief(d):
-    r = d.get("roofline", {})
+    r = d.get("roofline") or {}
     ks = {k: round(v, 4) for k, v in sorted(r.get("all_kernels_avg_ms", {}).items(), key=lambda kv: -kv[1]) if v > 0.02}
     return (f"{d['config'].get('name')}: {d['ms_per_step']} ms  {d['value']} {d['unit']}  parity={str(d.get('parity'))[:10]} "
             f"pipeline_frac={d.get('pipeline_frac_of_hbm_peak')}\n  phases={r.get('phases_avg_ms')}\n  kernels={ks}")
