@@ -163,8 +163,14 @@ __device__ __forceinline__ int next_pow2_clamped(int x, int lo, int hi) {
 __device__ __forceinline__ int log2_pow2(int p) { return 31 - __clz(p); }
 
 // power-of-two table for `items` distinct keys at load <= 1/2, clamped to [lo, hi]; `items` may be INT_MAX (saturated flops)
+// MULT = 4 (the wave-per-row and multi-wave hash kernels since round 4): a row that leaves room in its kernel's table gets
+// four slots per item instead of two.  In the lock-step insert loops every lane pays for the longest probe chain of the
+// trip, and the chains shorten with the load faster than the sweep of the larger table grows (measured: hash kernels -1 to
+// -4 % each; the 16-lane kernels, which sweep 16 slots at a time, lose with it and stay at 2; R-MCL tables at HALF the
+// size: +27 %).
+template <int MULT = 2>
 __device__ __forceinline__ int table_size(int items, int lo, int hi) {
-  return items >= hi / 2 ? hi : next_pow2_clamped(2 * items, lo, hi);
+  return items >= hi / MULT ? hi : next_pow2_clamped(MULT * items, lo, hi);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1321,7 +1327,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ 
       qn = next_row<QB>(qctr, &qslot, q);
       nxt = load_meta_sym(rows, qn, count, IA, rowFlops);
     }
-    const int size = table_size(cur.x0, 64, TBL);
+    const int size = table_size<4>(cur.x0, 64, TBL);
     const int shift = 32 - log2_pow2(size);
     clear_table(keys, nullptr, size, tid, WAVE * NW);
     if (tid == 0) cnt_s = 0;
@@ -1452,7 +1458,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
       q = qn;
       continue;
     }
-    const int size = table_size(want, T > 64 ? T : 64, TBL);
+    const int size = table_size<4>(want, T > 64 ? T : 64, TBL);
     const int shift = 32 - log2_pow2(size);
     clear_slots(tab, size, tid, T);
     if (NW > 1 && tid == 0) emitted = 0;
