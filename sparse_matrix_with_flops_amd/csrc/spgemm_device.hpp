@@ -359,6 +359,48 @@ __device__ __forceinline__ void lds_fadd_multi(float* acc, const int (&idx)[U], 
   }
 }
 
+// The R rounds of a trip (gathered together: one memory round trip) are INSERTED CH rounds at a time: in a lock-step probe
+// loop every round of the trip issues its CAS in every iteration until the longest chain among ALL its products has ended
+// (R = 8: the longest of 512 chains), so R/CH short loops issue fewer instructions than one long one, and the first of
+// them starts as soon as ITS gathers have landed.  Round 4, medians of 4 processes per arm: the wave-per-row kernels (R up
+// to 8) with CH = 4 / 2 / 1: symbolic 0.195 -> 0.189 / 0.177 / 0.172 ms, numeric 0.304 -> 0.298 / 0.289 / 0.284 (web
+// surrogate numeric 0.296 -> 0.280 at CH = 1); the multi-wave kernels (trips of 2 rounds) LOSE 2-4 % with CH = 1 and
+// keep their one loop.  CH <= 0: the whole trip in one loop.
+template <int NW> struct InsChunk { static constexpr int value = NW == 1 ? 1 : 0; };
+template <int CH, int R>
+__device__ __forceinline__ int hash_insert_chunked(int* keys, int size, int shift, const bool (&act)[R], const int (&col)[R],
+                                                   int* dummy, int* err) {
+  if constexpr (CH <= 0 || CH >= R) return hash_insert_multi(keys, size, shift, act, col, dummy, err);
+  else {
+    int claimed = 0;
+#pragma unroll
+    for (int c0 = 0; c0 < R; c0 += CH) {
+      bool a_[CH]; int c_[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) { a_[u] = c0 + u < R ? act[c0 + u < R ? c0 + u : 0] : false; c_[u] = col[c0 + u < R ? c0 + u : 0]; }
+      claimed += hash_insert_multi(keys, size, shift, a_, c_, dummy, err);
+    }
+    return claimed;
+  }
+}
+template <int CH, int R>
+__device__ __forceinline__ void hash_accum_chunked(slot_t* tab, int size, int shift, const bool (&act)[R], const int (&col)[R],
+                                                   const float (&val)[R], slot_t* dummy, int* err) {
+  if constexpr (CH <= 0 || CH >= R) hash_accum_multi(tab, size, shift, act, col, val, dummy, err);
+  else {
+#pragma unroll
+    for (int c0 = 0; c0 < R; c0 += CH) {
+      bool a_[CH]; int c_[CH]; float v_[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int i = c0 + u < R ? c0 + u : 0;
+        a_[u] = c0 + u < R ? act[i] : false; c_[u] = col[i]; v_[u] = val[i];
+      }
+      hash_accum_multi(tab, size, shift, a_, c_, v_, dummy, err);
+    }
+  }
+}
+
 // slot-table clear, two slots per lane and instruction
 __device__ __forceinline__ void clear_slots(slot_t* tab, int size, int tid, int nthreads) {
   for (int i = tid * 2; i < size; i += nthreads * 2) *reinterpret_cast<ulonglong2*>(tab + i) = make_ulonglong2(EMPTY_SLOT, EMPTY_SLOT);
@@ -1335,7 +1377,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_sym_hash(const int* __restrict__ 
     int mine = 0;
     for_each_product<NW, U, false>(st, cur.as, cur.ae, SBL, nullptr, JB, nullptr,
                                    [&](const auto& act, const auto& col, const auto& val, int) {
-      mine += hash_insert_multi(keys, size, shift, act, col, reinterpret_cast<int*>(&st.dummy[lane_id()]), err);
+      mine += hash_insert_chunked<InsChunk<NW>::value>(keys, size, shift, act, col, reinterpret_cast<int*>(&st.dummy[lane_id()]), err);
     }, pc, err);
     const int ws = wave_sum(mine);                           // hash_insert_multi counts per lane
     if (NW == 1) {
@@ -1470,7 +1512,7 @@ __global__ __launch_bounds__(WAVE * NW) void k_num_hash(const int* __restrict__ 
 #pragma unroll
         for (int u = 0; u < (int)(sizeof(col) / sizeof(col[0])); ++u) asm volatile("" :: "v"(col[u]), "v"(val[u]));
       } else
-      hash_accum_multi(tab, size, shift, act, col, val, &st.dummy[lane_id()], err);
+      hash_accum_chunked<InsChunk<NW>::value>(tab, size, shift, act, col, val, &st.dummy[lane_id()], err);
     }, pc, err);
     // compaction: wave w sweeps the contiguous slots [w*per, w*per+per) 64 at a time, so that a wave's stores
     // land on consecutive output positions.  One wave: a single pass.  Several waves: a wave reads its slots into
