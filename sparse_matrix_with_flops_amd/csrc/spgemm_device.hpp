@@ -366,6 +366,7 @@ __device__ __forceinline__ void lds_fadd_multi(float* acc, const int (&idx)[U], 
 // to 8) with CH = 4 / 2 / 1: symbolic 0.195 -> 0.189 / 0.177 / 0.172 ms, numeric 0.304 -> 0.298 / 0.289 / 0.284 (web
 // surrogate numeric 0.296 -> 0.280 at CH = 1); the multi-wave kernels (trips of 2 rounds) LOSE 2-4 % with CH = 1 and
 // keep their one loop.  CH <= 0: the whole trip in one loop.
+// (trips of 4 rounds inserted 2 at a time in the multi-wave kernels: no change; of 8: slower.)
 template <int NW> struct InsChunk { static constexpr int value = NW == 1 ? 1 : 0; };
 template <int CH, int R>
 __device__ __forceinline__ int hash_insert_chunked(int* keys, int size, int shift, const bool (&act)[R], const int (&col)[R],
