@@ -379,6 +379,7 @@ __device__ __forceinline__ int hash_insert_chunked(int* keys, int size, int shif
       bool a_[CH]; int c_[CH];
 #pragma unroll
       for (int u = 0; u < CH; ++u) { a_[u] = c0 + u < R ? act[c0 + u < R ? c0 + u : 0] : false; c_[u] = col[c0 + u < R ? c0 + u : 0]; }
+      if (CH == 1 && ballot64(a_[0]) == 0ull) continue;          // a round past the end of the group (5 rounds run as 6, 7 as 8)
       claimed += hash_insert_multi(keys, size, shift, a_, c_, dummy, err);
     }
     return claimed;
@@ -397,6 +398,7 @@ __device__ __forceinline__ void hash_accum_chunked(slot_t* tab, int size, int sh
         const int i = c0 + u < R ? c0 + u : 0;
         a_[u] = c0 + u < R ? act[i] : false; c_[u] = col[i]; v_[u] = val[i];
       }
+      if (CH == 1 && ballot64(a_[0]) == 0ull) continue;
       hash_accum_multi(tab, size, shift, a_, c_, v_, dummy, err);
     }
   }

@@ -28,4 +28,5 @@ for f in sorted(glob.glob(f'gpurun_out/{tag}_bench_*.json')):
     json.dump(d, open(f'profiles/{tag}_bench_{name}.json', 'w'))
     print(name, d['ms_per_step'], d['value'], r.get('kernel'), r.get('frac'), r.get('traffic_over_alg'))
 PY
+[ -f gpurun_out/${TAG}_sq_counters_1m.txt ] && cp gpurun_out/${TAG}_sq_counters_1m.txt profiles/
 cat gpurun_out/${TAG}_commit.txt 2>/dev/null || true
