@@ -20,4 +20,4 @@ for wl in synth_1m_16 web_google_surrogate synth_256k_16; do profiles/collect.sh
 OUT=$PWD/gpurun_out/prof_${TAG}_rmcl_500k; rm -rf $OUT; mkdir -p $OUT
 ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $OLDPWD/bench.py --workload rmcl_500k --steps 3 --warmup 1 --no-verify --no-cpu-baseline --no-host-api > $OUT/trace.log 2>&1; echo "rmcl trace exit=$?" )
 # SQ counters of the headline workload (three --pmc passes, kernel-trace only) -> gpurun_out/<tag>_sq_counters_1m.txt
-tools/pmc_sq.sh synth_1m_16 && python tools/pmc_sq.py gpurun_out/pmc_sq > gpurun_out/${TAG}_sq_counters_1m.txt
+bash tools/pmc_sq.sh synth_1m_16 && python tools/pmc_sq.py gpurun_out/pmc_sq > gpurun_out/${TAG}_sq_counters_1m.txt
