@@ -211,6 +211,7 @@ struct spgemm_handle {
   int bhCap = BH_CAP;
   int bhMargin = 125;                // parking region per hash class, % of products/npass (SPGEMM_BHMARGIN; tests force overflows)
   int h1sym = 32;                    // blocks per CU of the wave-per-row symbolic kernel (SPGEMM_H1SYM, experiments)
+  int h1num = 24;                    // ... of the wave-per-row numeric kernel on its 512-slot tables (SPGEMM_H1NUM)
   spgemm_stats stats;
   spgemm_host_api_stats host_api = {};   // phases of the latest hip_CSR_SpMM
   int failNext = 0;                  // test hook (spgemm_hip_debug_fail_next): the next symbolic phase / R-MCL step on this handle fails
@@ -291,6 +292,7 @@ extern "C" int spgemm_hip_create(spgemm_handle** out, int device) {
   { const char* e = getenv("SPGEMM_ABLATE"); int v = e ? atoi(e) : 0; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(smf::g_ablate), &v, sizeof(int))); }
 #endif
   { const char* e = getenv("SPGEMM_H1SYM"); if (e) { const int c = atoi(e); if (c >= 1 && c <= 32) h->h1sym = c; } }
+  { const char* e = getenv("SPGEMM_H1NUM"); if (e) { const int c = atoi(e); if (c >= 1 && c <= 32) h->h1num = c; } }
   { const char* e = getenv("SPGEMM_BHMARGIN"); if (e) { const int c = atoi(e); if (c >= 10 && c <= 400) h->bhMargin = c; } }
   { const char* e = getenv("SPGEMM_BHCAP"); if (e) { const int c = atoi(e); if (c >= 1024 && c <= BH_CAP_MAX) h->bhCap = c; } }
   { const char* e = getenv("SPGEMM_PATH"); if (e) { const int v = atoi(e); if (v >= 0 && v <= 2) h->pathMode = v; } }
@@ -645,7 +647,7 @@ static int launch_numeric(spgemm_handle* h, const int* dIA, const float* dA,
     const int* sb = h->dsmall->slotBase;
     const int* hs_ = h->mirror.slotBase;
     const int na = hs_[SLOT_H1A + 1] - hs_[SLOT_H1A], nb = hs_[SLOT_H1B + 1] - hs_[SLOT_H1B];
-    if (na > 0 && !skipH1A) LAUNCH_NUM(1, 512, dim3(grid8(na, cu * 24)), dim3(64), st, sb, SLOT_H1A,
+    if (na > 0 && !skipH1A) LAUNCH_NUM(1, 512, dim3(grid8(na, cu * h->h1num)), dim3(64), st, sb, SLOT_H1A,
                          rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7 * 32, h->rowFlops);
     if (nb > 0) LAUNCH_NUM(1, 1024, dim3(grid8(nb, cu * 16)), dim3(64), st, sb, SLOT_H1B,
                          rowIds, dIA, sbl, dA, dJB, dB, dIC, dJC, dC, err, qc + 7 * 32, h->rowFlops); }
