@@ -119,3 +119,12 @@ def test_one_pass_capacity_guard(monkeypatch):
     assert_parity(mul(h, A2, B2), want2, what="same shape and P, twice the entries: capacity guard + redo")
     assert_parity(mul(h, A1, B1), want1, what="and back")
     h.close()
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_more_than_2_pow_30_products_under_the_opt_in_paths(monkeypatch, path):
+    """Beyond 2^30 products C is not sized by P: the opt-in paths, which queue only part of the symbolic pass, hand the call
+    to the two-phase pipeline (tests/test_gpu_abi.py has the case; here it runs with the path selected)."""
+    monkeypatch.setenv("SPGEMM_PATH", str(path))
+    import test_gpu_abi
+    test_gpu_abi.test_more_than_2_pow_30_products_take_the_two_phase_path()
